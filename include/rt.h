@@ -1,0 +1,195 @@
+/* C ABI of the MI355X path-tracing hot path (librt_hip.so).
+ *
+ * The reference (Winter-Is-Coming-Stark/Raytracer, a Rust crate) has no FFI of its own: the hot path
+ * sits behind three traits and one function. Each entry point below names the reference interface it
+ * stands in for. A Rust host binds these with `extern "C"`; the Python package binds them with ctypes.
+ *
+ * Conventions: every pointer passed in or out is owned by the caller unless stated; the library owns
+ * all device memory; calls block until their result is ready; nothing unwinds or aborts across this
+ * boundary — every reference `panic!` site is an error code here. Return value 0 = ok, < 0 = error
+ * (text via rt_last_error / rt_builder_last_error). One rt_context (and one rt_builder) may be used
+ * from one host thread at a time. All geometry is IEEE f64 like the reference (vec3.rs:5-9).
+ */
+#ifndef RT_H
+#define RT_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,     /* bad argument / bad handle */
+    RT_ERR_UNSUPPORTED = -2, /* a scene shape the device path does not implement */
+    RT_ERR_NO_DEVICE = -3,   /* no HIP device, or HIP runtime error */
+    RT_ERR_OOM = -4,
+    RT_ERR_PANIC = -5        /* a condition on which the reference would panic */
+};
+
+/* ------------------------------------------------------------------------------------------------
+ * Scene building: the reference's constructors, flattened to handles.
+ * A handle is a non-negative int; negative = error code. Textures, materials and hittables have
+ * separate handle spaces. Hittable handles are issued 0,1,2,... in creation order and are the
+ * `prim_id` reported by rt_trace_first_hit.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct rt_builder rt_builder;
+
+/* `seed` drives the randomness the reference takes from thread_rng() while BUILDING a scene:
+ * BVH split axes (bvh.rs:22) and Perlin tables (perlin.rs:28-54). */
+rt_builder* rt_builder_new(uint64_t seed);
+void rt_builder_free(rt_builder*);
+const char* rt_builder_last_error(const rt_builder*);
+/* flags: bit 0 = RotateY keeps its rotated bounding box (book behaviour) instead of discarding it
+ * (hittable.rs:117-143). Default 0 = as the reference. Set before creating RotateY objects. */
+int rt_builder_set_flags(rt_builder*, uint32_t flags);
+
+/* Texture (texture.rs:8-10) */
+int rt_tex_solid(rt_builder*, double r, double g, double b);          /* SolidColor::new, texture.rs:18 */
+int rt_tex_checker(rt_builder*, int even_tex, int odd_tex);           /* CheckerTexture::new, /root/reference/texture.rs:40-48 */
+int rt_tex_noise(rt_builder*, double scale);                          /* NoiseTexture::new, texture.rs:63-70 */
+/* ImageTexture::new (texture.rs:90-103) with the decode already done: tightly packed RGB8, row 0 = top. */
+int rt_tex_image(rt_builder*, const uint8_t* rgb8, uint32_t width, uint32_t height);
+
+/* Material (material.rs:10-22) */
+int rt_mat_lambertian(rt_builder*, int albedo_tex);                   /* Lambertian::new_by_pointer, material.rs:36 */
+int rt_mat_metal(rt_builder*, double r, double g, double b, double fuzz); /* Metal::new, material.rs:68-77 (fuzz clamped to <= 1) */
+int rt_mat_dielectric(rt_builder*, double ir);                        /* Dielectric::new, material.rs:105 */
+int rt_mat_diffuse_light(rt_builder*, int emit_tex, double k);        /* DiffuseLight{emit,k}, material.rs:153-189 */
+int rt_mat_isotropic(rt_builder*, int albedo_tex);                    /* Isotropic, material.rs:207-217 */
+
+/* Hittable (hittable.rs:48-51) */
+int rt_sphere(rt_builder*, const double center[3], double radius, int mat);                 /* sphere.rs:16 */
+int rt_moving_sphere(rt_builder*, const double c0[3], const double c1[3], double time0, double time1,
+                     double radius, int mat);                                               /* moving_sphere.rs:19 */
+int rt_xy_rect(rt_builder*, double x0, double x1, double y0, double y1, double k, int mat); /* arrect.rs:18 */
+int rt_xz_rect(rt_builder*, double x0, double x1, double z0, double z1, double k, int mat); /* arrect.rs:70 */
+int rt_yz_rect(rt_builder*, double y0, double y1, double z0, double z1, double k, int mat); /* arrect.rs:122 */
+int rt_box(rt_builder*, const double p0[3], const double p1[3], int mat);                   /* _box.rs:15 */
+int rt_translate(rt_builder*, int child, const double offset[3]);                           /* hittable.rs:61 */
+int rt_rotate_y(rt_builder*, int child, double angle_degrees);                              /* hittable.rs:104 */
+int rt_constant_medium(rt_builder*, int boundary, double density, double r, double g, double b); /* constant_medium.rs:15 */
+int rt_list_new(rt_builder*);                                                               /* hittable_list.rs:27 */
+int rt_list_add(rt_builder*, int list, int child);                                          /* hittable_list.rs:15 */
+/* BvhNode::new_(list, time0, time1) (bvh.rs:68-71). Sorts `list` in place like the reference.
+ * RT_ERR_PANIC if a member has no bounding box (bvh.rs:58,77). */
+int rt_bvh(rt_builder*, int list, double time0, double time1);
+
+/* Flatten the object graph below `world_list` into a relocatable blob (malloc'ed; free with rt_free).
+ * RT_ERR_UNSUPPORTED for shapes the device path does not take: a ConstantMedium whose boundary is not a
+ * primitive/box under at most RT_MAX_CHAIN Translate/RotateY, or instance nesting deeper than that. */
+int rt_builder_compile(rt_builder*, int world_list, void** blob, size_t* nbytes);
+/* The same scene as a replayable text log of the constructor calls above (exact hex floats), for an
+ * independent implementation to rebuild the object graph from. malloc'ed; free with rt_free. */
+int rt_builder_describe(rt_builder*, int world_list, char** text, size_t* nbytes);
+void rt_free(void*);
+
+/* Ready-made scenes: the reference's scene functions (main.rs:260-835) and two scaled-up variants.
+ * Names: "final_scene", "cornell_box", "cornell_smoke", "random_scene", "two_spheres",
+ * "two_perlin_spheres", "earth", "simple_light", "spheres_grid" (n = spheres), "stress_volume".
+ * Scene randomness (box heights, sphere centres, materials) comes from `scene_seed`.
+ * "earthmap.jpg" must be registered first for scenes that open it (texture.rs:91 would panic). */
+typedef struct {
+    double from[3], at[3], vup[3], vfov, aspect, aperture, focus, time0, time1; /* Camera::new inputs, camera.rs:21-29 */
+} rt_camera;
+typedef struct {
+    int world;                 /* hittable handle of the world list */
+    rt_camera camera;          /* the camera that goes with the scene */
+    double background[3];
+    uint32_t background_mode;  /* 0 constant, 1 sky gradient */
+    uint32_t width, height, spp, max_depth; /* the configuration's image */
+} rt_scene_info;
+int rt_builder_register_image(rt_builder*, const char* filename, const uint8_t* rgb8, uint32_t width, uint32_t height);
+int rt_build_named_scene(rt_builder*, const char* name, uint64_t scene_seed, uint64_t n, rt_scene_info* info);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device side
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct rt_context rt_context; /* one per process: a HIP device, a stream, work buffers */
+typedef struct rt_scene rt_scene;     /* device-resident copy of a compiled blob */
+
+/* Ray + the t_min/t_max arguments of Hittable::hit (ray.rs:5-9, hittable.rs:49) */
+typedef struct { double ox, oy, oz, dx, dy, dz, time, tmin, tmax; } rt_ray_d;
+/* HitRecord (hittable.rs:9-18) plus the identity of what was hit */
+typedef struct {
+    double t;
+    uint32_t prim_id;     /* hittable handle of the Sphere/MovingSphere/rect/_Box/ConstantMedium hit; 0xFFFFFFFF = miss */
+    uint32_t flags;       /* bit 0 hit, bit 1 front_face, bits 4-6 box face (order of _box.rs:22-71) */
+    double px, py, pz, nx, ny, nz, u, v;
+    uint32_t material_id; /* material handle */
+    uint32_t pad;
+} rt_hit;
+#define RT_HIT_FLAG_HIT 1u
+#define RT_HIT_FLAG_FRONT 2u
+#define RT_MISS 0xFFFFFFFFu
+
+typedef struct {
+    uint32_t width, height;
+    uint32_t max_depth;        /* main.rs:79 */
+    uint32_t background_mode;  /* 0 = constant `background` (main.rs:56-58); 1 = sky gradient of the older snapshot (/root/reference/main.rs:59-61) */
+    double background[3];
+    uint64_t seed;             /* render seed: Philox key material */
+    uint32_t compat;           /* bit 0: book-correct RotateY back-rotation (else hittable.rs:167-171 as written);
+                                  bit 1: book-correct XY lens disk (else vec3.rs:105 / camera.rs:58 as written) */
+    uint32_t tile;             /* tile edge in pixels for multi-GPU sharding; 0 = default 32 */
+    uint32_t tile_rank, tile_world; /* this context renders tiles k with k % tile_world == tile_rank; world 0/1 = everything */
+    uint32_t spp_per_pass;     /* camera samples per pixel traced together; 0 = choose from the path budget */
+    uint32_t profile;          /* 1 = bracket every kernel launch with HIP events (fills the *_ms fields) */
+    uint32_t pad;
+} rt_params;
+
+typedef struct {
+    uint64_t camera_samples;   /* iterations of main.rs:161-167 */
+    uint64_t ray_segments;     /* world.hit calls issued by ray_color (main.rs:56), primary included */
+    uint64_t medium_tests;     /* ConstantMedium::hit calls (constant_medium.rs:25), not counted as rays */
+    uint64_t passes;
+    double seconds_render;     /* host wall clock around the device work */
+    double raygen_ms, extend_ms, shade_ms[5], accumulate_ms;  /* HIP-event sums when profile = 1 */
+    uint64_t raygen_launches, extend_launches, shade_launches, accumulate_launches;
+    uint64_t extend_segments;  /* segments traced by the timed extend launches */
+} rt_stats;
+
+int rt_init(rt_context** out, int device);  /* RT_ERR_NO_DEVICE when HIP reports no usable device */
+void rt_shutdown(rt_context*);
+const char* rt_last_error(const rt_context*);
+
+int rt_scene_upload(rt_context*, const void* blob, size_t nbytes, rt_scene** out);             /* host blob */
+int rt_scene_upload_from_device(rt_context*, const void* d_blob, size_t nbytes, rt_scene** out); /* blob already in HBM (after an RCCL broadcast) */
+void rt_scene_free(rt_context*, rt_scene*);
+
+/* Hittable::hit of the world list for a batch of rays: out[i] = what world.hit(rays[i], tmin, tmax, rec)
+ * (hittable_list.rs:40-53) leaves in rec. medium_xi: n * n_media uniforms, row i = the value each
+ * ConstantMedium would draw at constant_medium.rs:53 for ray i (medium order = creation order);
+ * NULL = ConstantMedium objects never hit. */
+int rt_trace_first_hit(rt_context*, const rt_scene*, const rt_ray_d* rays, size_t n, const double* medium_xi,
+                       rt_hit* out);
+
+/* Camera::get_ray behind the pixel jitter (main.rs:162-164, camera.rs:56-64) for sample `sample` of each
+ * pixel: out[(y*width + x)] for the whole image. For tests. */
+int rt_generate_rays(rt_context*, const rt_camera*, const rt_params*, uint32_t sample, rt_ray_d* out);
+
+/* The sample loop (main.rs:155-168) for samples [sample_offset, sample_offset+spp) of this context's
+ * tiles: adds each sample's ray_color, in sample order, to d_rgb_sum — a DEVICE buffer of
+ * width*height*3 doubles, row y <-> v = y/(height-1) (row 0 is the bottom of the view, main.rs:163,170).
+ * Pixels of other ranks' tiles are left untouched. stats (nullable) is accumulated into. */
+int rt_render_accumulate(rt_context*, const rt_scene*, const rt_camera*, const rt_params*,
+                         uint32_t sample_offset, uint32_t spp, double* d_rgb_sum, rt_stats* stats);
+
+/* Whole job with host buffers: rgb_sum_out = width*height*3 linear radiance sums over `spp` samples;
+ * rgb8_out (nullable) = the reference's pixel conversion (main.rs:172-189). */
+int rt_render(rt_context*, const rt_scene*, const rt_camera*, const rt_params*, uint32_t spp,
+              double* rgb_sum_out, uint8_t* rgb8_out, rt_stats* stats);
+
+/* main.rs:172-189 on the host for an already gathered sum buffer */
+void rt_tonemap(const double* rgb_sum, size_t n_pixels, double spp, uint8_t* rgb8_out);
+
+/* Device memory for callers without their own allocator (freed by rt_device_free). */
+int rt_device_alloc(rt_context*, size_t nbytes, void** d_ptr);
+int rt_device_free(rt_context*, void* d_ptr);
+int rt_device_memset(rt_context*, void* d_ptr, int value, size_t nbytes);
+int rt_device_download(rt_context*, void* host_dst, const void* d_src, size_t nbytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_H */

@@ -1,0 +1,713 @@
+// Host scene builder and scene compiler.
+//
+// rt_builder keeps the object graph the reference would hold as Arc<dyn Hittable/Material/Texture>
+// (one record per constructor call), builds BVHs with the reference's algorithm at construction time
+// (raytracer/src/bvh.rs:15-71), and flattens the graph below a world list into the blob described in
+// rt_types.h. It also keeps a replayable log of every constructor call.
+#include "rt_builder.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+
+const double kInf = std::numeric_limits<double>::infinity();
+
+AABB surrounding_box(const AABB& a, const AABB& b) { // aabb.rs:77-91
+    AABB o;
+    for (int i = 0; i < 3; ++i) {
+        o.lo[i] = rt_fmin(a.lo[i], b.lo[i]);
+        o.hi[i] = rt_fmax(a.hi[i], b.hi[i]);
+    }
+    return o;
+}
+
+void append_fmt(std::string& s, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    int n = vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (n > 0) s.append(buf, (size_t)std::min<int>(n, (int)sizeof buf - 1));
+}
+
+float round_down_f32(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+    return f;
+}
+float round_up_f32(double v) {
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+    return f;
+}
+
+} // namespace
+
+// ---- sequential uniform stream ----------------------------------------------------------------------
+double SeqRng::next() {
+    if (have_spare) { have_spare = false; return spare; }
+    Philox4 p = philox4x32_10((uint32_t)counter, (uint32_t)(counter >> 32), 0x5EEDu, stream, (uint32_t)seed,
+                              (uint32_t)(seed >> 32));
+    ++counter;
+    spare = rt_u01(p.v[2], p.v[3]);
+    have_spare = true;
+    return rt_u01(p.v[0], p.v[1]);
+}
+double SeqRng::range(double lo, double hi) { return rt_range(next(), lo, hi); } // rtweekend.rs:19-22
+int SeqRng::irange(int lo, int hi) {                                            // rtweekend.rs:24-27
+    int v = lo + (int)std::floor(next() * (double)(hi - lo));
+    return v >= hi ? hi - 1 : v;
+}
+
+// ---- builder ------------------------------------------------------------------------------------------
+int rt_builder::fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    error = buf;
+    return code;
+}
+
+bool rt_builder::valid_obj(int h) const { return h >= 0 && (size_t)h < objs.size(); }
+bool rt_builder::valid_mat(int h) const { return h >= 0 && (size_t)h < mats.size(); }
+bool rt_builder::valid_tex(int h) const { return h >= 0 && (size_t)h < texs.size(); }
+
+int rt_builder::add_obj(ObjRec o) {
+    objs.push_back(std::move(o));
+    return (int)objs.size() - 1;
+}
+
+// Hittable::bounding_box for every kind, with the reference's quirks.
+bool rt_builder::bounding_box(int h, double t0, double t1, AABB& out) const {
+    const ObjRec& o = objs[h];
+    switch (o.kind) {
+    case OBJ_SPHERE: // sphere.rs:66-72
+        for (int i = 0; i < 3; ++i) { out.lo[i] = o.d[i] - o.d[3]; out.hi[i] = o.d[i] + o.d[3]; }
+        return true;
+    case OBJ_MSPHERE: { // moving_sphere.rs:71-84
+        AABB b0, b1;
+        const double tt[2] = {t0, t1};
+        AABB* bb[2] = {&b0, &b1};
+        for (int k = 0; k < 2; ++k)
+            for (int i = 0; i < 3; ++i) {
+                // center(time) = c0 + (c1 - c0) * (time - time0) / (time1 - time0), moving_sphere.rs:37-40
+                double c = o.d[i] + (o.d[3 + i] - o.d[i]) * (tt[k] - o.d[6]) / (o.d[7] - o.d[6]);
+                bb[k]->lo[i] = c - o.d[8];
+                bb[k]->hi[i] = c + o.d[8];
+            }
+        out = surrounding_box(b0, b1);
+        return true;
+    }
+    case OBJ_XYRECT: // arrect.rs:51-57
+        out.lo[0] = o.d[0]; out.lo[1] = o.d[2]; out.lo[2] = o.d[4] - 0.0001;
+        out.hi[0] = o.d[1]; out.hi[1] = o.d[3]; out.hi[2] = o.d[4] + 0.0001;
+        return true;
+    case OBJ_XZRECT: // arrect.rs:103-109
+        out.lo[0] = o.d[0]; out.lo[1] = o.d[4] - 0.0001; out.lo[2] = o.d[2];
+        out.hi[0] = o.d[1]; out.hi[1] = o.d[4] + 0.0001; out.hi[2] = o.d[3];
+        return true;
+    case OBJ_YZRECT: // arrect.rs:155-161
+        out.lo[0] = o.d[4] - 0.0001; out.lo[1] = o.d[0]; out.lo[2] = o.d[2];
+        out.hi[0] = o.d[4] + 0.0001; out.hi[1] = o.d[1]; out.hi[2] = o.d[3];
+        return true;
+    case OBJ_BOX: // _box.rs:81-84
+        for (int i = 0; i < 3; ++i) { out.lo[i] = o.d[i]; out.hi[i] = o.d[3 + i]; }
+        return true;
+    case OBJ_TRANSLATE: { // hittable.rs:81-90
+        if (!bounding_box(o.child, t0, t1, out)) return false;
+        for (int i = 0; i < 3; ++i) { out.lo[i] = out.lo[i] + o.d[i]; out.hi[i] = out.hi[i] + o.d[i]; }
+        return true;
+    }
+    case OBJ_ROTATE_Y: // hittable.rs:179-182: the box captured at construction
+        out = o.box;
+        return o.hasbox;
+    case OBJ_MEDIUM: // constant_medium.rs:68-70
+        return bounding_box(o.child, t0, t1, out);
+    case OBJ_LIST: { // hittable_list.rs:55-75: first_box is never cleared, so the last member's box wins
+        if (o.members.empty()) return false;
+        AABB temp;
+        temp.lo[0] = temp.lo[1] = temp.lo[2] = temp.hi[0] = temp.hi[1] = temp.hi[2] = 0.0;
+        for (int m : o.members) {
+            if (!bounding_box(m, t0, t1, temp)) return false;
+            out = temp;
+        }
+        return true;
+    }
+    case OBJ_BVH: // bvh.rs:124-127
+        out = o.box;
+        return true;
+    }
+    return false;
+}
+
+// BvhNode::new (bvh.rs:15-66). Returns the index of the node created in `tree`, or -1 after fail().
+int rt_builder::build_bvh_node(std::vector<BNode>& tree, std::vector<int>& objects, const std::vector<double>& keys,
+                               size_t start, size_t end, double t0, double t1) {
+    const int axis = rng.irange(0, 3);
+    axis_log.push_back((char)('0' + axis));
+    auto less = [&](int a, int b) { return keys[(size_t)a * 3 + axis] < keys[(size_t)b * 3 + axis]; };
+    const size_t span = end - start;
+    const int me = (int)tree.size();
+    tree.push_back(BNode());
+    int left_obj = -1, right_obj = -1, left_node = -1, right_node = -1;
+    if (span == 1) {
+        left_obj = right_obj = objects[start];
+    } else if (span == 2) {
+        if (less(objects[start], objects[start + 1])) { left_obj = objects[start]; right_obj = objects[start + 1]; }
+        else { left_obj = objects[start + 1]; right_obj = objects[start]; }
+    } else {
+        std::stable_sort(objects.begin() + (long)start, objects.begin() + (long)end, less);
+        const size_t mid = start + span / 2;
+        left_node = build_bvh_node(tree, objects, keys, start, mid, t0, t1);
+        if (left_node < 0) return -1;
+        right_node = build_bvh_node(tree, objects, keys, mid, end, t0, t1);
+        if (right_node < 0) return -1;
+    }
+    AABB bl, br;
+    bool okl = left_node >= 0 ? (bl = tree[left_node].box, true) : bounding_box(left_obj, t0, t1, bl);
+    bool okr = right_node >= 0 ? (br = tree[right_node].box, true) : bounding_box(right_obj, t0, t1, br);
+    if (!okl || !okr) { fail(RT_ERR_PANIC, "No bounding box in bvh_node constructor"); return -1; }
+    BNode& n = tree[me];
+    n.box = surrounding_box(bl, br);
+    n.left_node = left_node; n.right_node = right_node;
+    n.left_obj = left_obj; n.right_obj = right_obj;
+    return me;
+}
+
+// ---- flattening -----------------------------------------------------------------------------------------
+struct rt_builder::Flat {
+    std::vector<RtNode> nodes;
+    std::vector<RtSphere> spheres; std::vector<RtMeta> sphere_meta;
+    std::vector<RtMSphere> mspheres; std::vector<RtMeta> msphere_meta;
+    std::vector<RtRect> rects; std::vector<RtMeta> rect_meta;
+    std::vector<RtBox> boxes; std::vector<RtMeta> box_meta;
+    std::vector<RtMedium> media;
+    std::vector<RtInst> insts;
+    std::vector<uint32_t> list_entries;
+    uint32_t max_chain = 0;
+    uint32_t n_media = 0;
+};
+
+namespace {
+RtMeta make_meta(const ObjRec& o, int handle, int parent) {
+    RtMeta m;
+    m.material = (uint32_t)o.mat; m.parent_inst = parent; m.src_id = (uint32_t)handle; m.pad = 0;
+    return m;
+}
+}
+
+// Emits object `h` (and everything below it) seen under instance `parent`, `depth` instances deep.
+// Returns its ref, or RT_REF_NONE after fail(). need = worst-case stack growth while it is processed.
+uint32_t rt_builder::emit(Flat& f, int h, int parent, uint32_t depth, uint32_t& need) {
+    const ObjRec& o = objs[h];
+    need = 0;
+    switch (o.kind) {
+    case OBJ_SPHERE: {
+        RtSphere s = {o.d[0], o.d[1], o.d[2], o.d[3]};
+        f.spheres.push_back(s);
+        f.sphere_meta.push_back(make_meta(o, h, parent));
+        return RT_MAKE_REF(RT_REF_SPHERE, f.spheres.size() - 1);
+    }
+    case OBJ_MSPHERE: {
+        RtMSphere s;
+        for (int i = 0; i < 3; ++i) { s.c0[i] = o.d[i]; s.c1[i] = o.d[3 + i]; }
+        s.t0 = o.d[6]; s.t1 = o.d[7]; s.r = o.d[8]; s.pad = 0.0;
+        f.mspheres.push_back(s);
+        f.msphere_meta.push_back(make_meta(o, h, parent));
+        return RT_MAKE_REF(RT_REF_MSPHERE, f.mspheres.size() - 1);
+    }
+    case OBJ_XYRECT: case OBJ_XZRECT: case OBJ_YZRECT: {
+        RtRect q;
+        q.a0 = o.d[0]; q.a1 = o.d[1]; q.b0 = o.d[2]; q.b1 = o.d[3]; q.k = o.d[4];
+        q.axis = o.kind == OBJ_XYRECT ? 0u : (o.kind == OBJ_XZRECT ? 1u : 2u);
+        q.pad = 0;
+        f.rects.push_back(q);
+        f.rect_meta.push_back(make_meta(o, h, parent));
+        return RT_MAKE_REF(RT_REF_RECT, f.rects.size() - 1);
+    }
+    case OBJ_BOX: {
+        RtBox b;
+        for (int i = 0; i < 3; ++i) { b.p0[i] = o.d[i]; b.p1[i] = o.d[3 + i]; }
+        f.boxes.push_back(b);
+        f.box_meta.push_back(make_meta(o, h, parent));
+        return RT_MAKE_REF(RT_REF_BOX, f.boxes.size() - 1);
+    }
+    case OBJ_TRANSLATE: case OBJ_ROTATE_Y: {
+        if (depth + 1 > RT_MAX_CHAIN) {
+            fail(RT_ERR_UNSUPPORTED, "object %d: more than %d nested Translate/RotateY", h, RT_MAX_CHAIN);
+            return RT_REF_NONE;
+        }
+        f.max_chain = std::max(f.max_chain, depth + 1);
+        const uint32_t me = (uint32_t)f.insts.size();
+        RtInst in;
+        in.a = o.d[0]; in.b = o.d[1]; in.c = o.d[2];
+        in.op = o.kind == OBJ_TRANSLATE ? RT_OP_TRANSLATE : RT_OP_ROTATE_Y;
+        in.child = RT_REF_NONE; in.parent_inst = parent; in.src_id = (uint32_t)h;
+        f.insts.push_back(in);
+        uint32_t cneed;
+        uint32_t c = emit(f, o.child, (int)me, depth + 1, cneed);
+        if (c == RT_REF_NONE) return RT_REF_NONE;
+        f.insts[me].child = c;
+        need = std::max(2u, 1u + cneed);
+        return RT_MAKE_REF(RT_REF_INST, me);
+    }
+    case OBJ_MEDIUM: {
+        // boundary: primitive or box below at most RT_MAX_CHAIN instances
+        int b = o.child;
+        uint32_t d = depth;
+        while (objs[b].kind == OBJ_TRANSLATE || objs[b].kind == OBJ_ROTATE_Y) { b = objs[b].child; ++d; }
+        const ObjKind bk = objs[b].kind;
+        if (!(bk == OBJ_SPHERE || bk == OBJ_MSPHERE || bk == OBJ_XYRECT || bk == OBJ_XZRECT || bk == OBJ_YZRECT ||
+              bk == OBJ_BOX) || d > RT_MAX_CHAIN) {
+            fail(RT_ERR_UNSUPPORTED, "ConstantMedium %d: boundary must be a sphere, moving sphere, rect or box under at most %d Translate/RotateY",
+                 h, RT_MAX_CHAIN);
+            return RT_REF_NONE;
+        }
+        uint32_t bneed;
+        uint32_t bref = emit(f, o.child, parent, depth, bneed);
+        if (bref == RT_REF_NONE) return RT_REF_NONE;
+        RtMedium m;
+        m.neg_inv_density = o.d[0];
+        m.boundary = bref; m.material = (uint32_t)o.mat; m.parent_inst = parent; m.src_id = (uint32_t)h;
+        m.medium_index = (uint32_t)o.medium_index; m.pad = 0;
+        f.media.push_back(m);
+        return RT_MAKE_REF(RT_REF_MEDIUM, f.media.size() - 1);
+    }
+    case OBJ_LIST: {
+        std::vector<uint32_t> refs;
+        uint32_t worst = 0;
+        for (int m : o.members) {
+            uint32_t cneed;
+            uint32_t r = emit(f, m, parent, depth, cneed);
+            if (r == RT_REF_NONE) return RT_REF_NONE;
+            refs.push_back(r);
+            worst = std::max(worst, cneed);
+        }
+        const uint32_t first = (uint32_t)f.list_entries.size();
+        for (uint32_t r : refs) f.list_entries.push_back(r);
+        f.list_entries.push_back(RT_REF_NONE);
+        need = refs.empty() ? 0u : std::max(2u, 1u + worst);
+        return RT_MAKE_REF(RT_REF_LIST, first);
+    }
+    case OBJ_BVH: {
+        uint32_t r = emit_bvh(f, o, 0, parent, depth, need);
+        return r;
+    }
+    }
+    fail(RT_ERR_INVALID, "object %d: unknown kind", h);
+    return RT_REF_NONE;
+}
+
+uint32_t rt_builder::emit_bvh(Flat& f, const ObjRec& o, int node, int parent, uint32_t depth, uint32_t& need) {
+    const BNode& bn = o.tree[(size_t)node];
+    const uint32_t me = (uint32_t)f.nodes.size();
+    RtNode n;
+    for (int i = 0; i < 3; ++i) { n.lo[i] = round_down_f32(bn.box.lo[i]); n.hi[i] = round_up_f32(bn.box.hi[i]); }
+    n.left = n.right = RT_REF_NONE;
+    f.nodes.push_back(n);
+    uint32_t lneed = 0, rneed = 0, l, r = RT_REF_NONE;
+    if (bn.left_node >= 0) l = emit_bvh(f, o, bn.left_node, parent, depth, lneed);
+    else l = emit(f, bn.left_obj, parent, depth, lneed);
+    if (l == RT_REF_NONE) return RT_REF_NONE;
+    if (bn.right_node >= 0) {
+        r = emit_bvh(f, o, bn.right_node, parent, depth, rneed);
+        if (r == RT_REF_NONE) return RT_REF_NONE;
+    } else if (bn.right_obj != bn.left_obj || objs[bn.right_obj].kind == OBJ_MEDIUM) {
+        // span-1 nodes (bvh.rs:33-35) hold the same object twice; the second test can never win for a
+        // surface, so it is dropped. A medium keeps both tests.
+        r = emit(f, bn.right_obj, parent, depth, rneed);
+        if (r == RT_REF_NONE) return RT_REF_NONE;
+    }
+    f.nodes[me].left = l;
+    f.nodes[me].right = r;
+    need = std::max(std::max(2u, 1u + lneed), rneed);
+    return RT_MAKE_REF(RT_REF_NODE, me);
+}
+
+namespace {
+template <class T>
+void put_section(std::vector<uint8_t>& blob, RtSection& sec, const std::vector<T>& v) {
+    size_t off = (blob.size() + 255u) & ~(size_t)255u;
+    blob.resize(off + v.size() * sizeof(T));
+    if (!v.empty()) memcpy(blob.data() + off, v.data(), v.size() * sizeof(T));
+    sec.offset = off;
+    sec.count = v.size();
+}
+}
+
+int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
+    if (!blob_out || !nbytes) return fail(RT_ERR_INVALID, "null output");
+    if (!valid_obj(world)) return fail(RT_ERR_INVALID, "world handle %d is not a hittable", world);
+    Flat f;
+    uint32_t need = 0;
+    uint32_t wref;
+    if (objs[world].kind == OBJ_LIST) {
+        wref = emit(f, world, RT_NO_PARENT, 0, need);
+    } else { // ray_color takes a HittableList (main.rs:49): wrap anything else in a one-entry list
+        uint32_t cneed;
+        uint32_t r = emit(f, world, RT_NO_PARENT, 0, cneed);
+        if (r == RT_REF_NONE) return RT_ERR_UNSUPPORTED;
+        const uint32_t first = (uint32_t)f.list_entries.size();
+        f.list_entries.push_back(r);
+        f.list_entries.push_back(RT_REF_NONE);
+        need = std::max(2u, 1u + cneed);
+        wref = RT_MAKE_REF(RT_REF_LIST, first);
+    }
+    if (wref == RT_REF_NONE) return error.empty() ? fail(RT_ERR_UNSUPPORTED, "empty scene") : RT_ERR_UNSUPPORTED;
+    const uint32_t stack_need = std::max(1u, need) + 1u;
+    if (stack_need > RT_STACK_CAP)
+        return fail(RT_ERR_UNSUPPORTED, "scene needs a traversal stack of %u entries, capacity is %u", stack_need, RT_STACK_CAP);
+
+    std::vector<RtMaterial> dmats;
+    for (const MatRec& m : mats) {
+        RtMaterial d;
+        d.type = m.type; d.tex = (uint32_t)std::max(0, m.tex);
+        for (int i = 0; i < 4; ++i) d.p[i] = m.p[i];
+        dmats.push_back(d);
+    }
+    std::vector<RtTexture> dtex;
+    std::vector<uint8_t> texels;
+    std::vector<double> pvec;
+    std::vector<int32_t> pperm;
+    for (const TexRec& t : texs) {
+        RtTexture d;
+        memset(&d, 0, sizeof d);
+        d.type = t.type;
+        switch (t.type) {
+        case RT_TEX_SOLID: d.p[0] = t.p[0]; d.p[1] = t.p[1]; d.p[2] = t.p[2]; break;
+        case RT_TEX_CHECKER: d.a = (uint32_t)t.a; d.b = (uint32_t)t.b; break;
+        case RT_TEX_NOISE:
+            d.a = (uint32_t)(pvec.size() / (RT_PERLIN_POINTS * 3));
+            d.p[0] = t.p[0];
+            pvec.insert(pvec.end(), t.perlin_vec.begin(), t.perlin_vec.end());
+            pperm.insert(pperm.end(), t.perlin_perm.begin(), t.perlin_perm.end());
+            break;
+        case RT_TEX_IMAGE: {
+            size_t off = (texels.size() + 15u) & ~(size_t)15u;
+            texels.resize(off + t.texels.size());
+            memcpy(texels.data() + off, t.texels.data(), t.texels.size());
+            d.a = (uint32_t)off; d.b = t.width; d.c = t.height;
+            break;
+        }
+        }
+        dtex.push_back(d);
+    }
+
+    std::vector<uint8_t> blob(sizeof(RtBlobHeader));
+    RtBlobHeader hd;
+    memset(&hd, 0, sizeof hd);
+    put_section(blob, hd.nodes, f.nodes);
+    put_section(blob, hd.spheres, f.spheres); put_section(blob, hd.sphere_meta, f.sphere_meta);
+    put_section(blob, hd.mspheres, f.mspheres); put_section(blob, hd.msphere_meta, f.msphere_meta);
+    put_section(blob, hd.rects, f.rects); put_section(blob, hd.rect_meta, f.rect_meta);
+    put_section(blob, hd.boxes, f.boxes); put_section(blob, hd.box_meta, f.box_meta);
+    put_section(blob, hd.media, f.media);
+    put_section(blob, hd.insts, f.insts);
+    put_section(blob, hd.list_entries, f.list_entries);
+    put_section(blob, hd.materials, dmats);
+    put_section(blob, hd.textures, dtex);
+    put_section(blob, hd.perlin_vec, pvec);
+    put_section(blob, hd.perlin_perm, pperm);
+    put_section(blob, hd.texels, texels);
+    blob.resize((blob.size() + 255u) & ~(size_t)255u);
+    hd.magic = RT_BLOB_MAGIC; hd.version = RT_BLOB_VERSION;
+    hd.total_bytes = blob.size();
+    hd.world = wref;
+    hd.n_media = (uint32_t)n_media;
+    hd.stack_need = stack_need;
+    hd.max_chain = f.max_chain;
+    hd.flags = flags;
+    hd.n_objects = (uint32_t)objs.size();
+    memcpy(blob.data(), &hd, sizeof hd);
+    void* out = malloc(blob.size());
+    if (!out) return fail(RT_ERR_OOM, "out of memory");
+    memcpy(out, blob.data(), blob.size());
+    *blob_out = out;
+    *nbytes = blob.size();
+    return RT_OK;
+}
+
+// ---- C entry points ---------------------------------------------------------------------------------------
+extern "C" {
+
+rt_builder* rt_builder_new(uint64_t seed) {
+    rt_builder* b = new (std::nothrow) rt_builder();
+    if (!b) return nullptr;
+    b->rng.seed = seed; b->rng.stream = 1;
+    b->log = "rtdesc 1\n";
+    return b;
+}
+void rt_builder_free(rt_builder* b) { delete b; }
+const char* rt_builder_last_error(const rt_builder* b) { return b ? b->error.c_str() : "null builder"; }
+int rt_builder_set_flags(rt_builder* b, uint32_t flags) {
+    if (!b) return RT_ERR_INVALID;
+    b->flags = flags;
+    append_fmt(b->log, "flags %u\n", flags);
+    return RT_OK;
+}
+void rt_free(void* p) { free(p); }
+
+int rt_tex_solid(rt_builder* b, double r, double g, double bl) {
+    if (!b) return RT_ERR_INVALID;
+    TexRec t; t.type = RT_TEX_SOLID; t.p[0] = r; t.p[1] = g; t.p[2] = bl;
+    b->texs.push_back(t);
+    int id = (int)b->texs.size() - 1;
+    append_fmt(b->log, "tex_solid %d %a %a %a\n", id, r, g, bl);
+    return id;
+}
+int rt_tex_checker(rt_builder* b, int even_tex, int odd_tex) {
+    if (!b) return RT_ERR_INVALID;
+    if (!b->valid_tex(even_tex) || !b->valid_tex(odd_tex)) return b->fail(RT_ERR_INVALID, "checker: bad texture handle");
+    TexRec t; t.type = RT_TEX_CHECKER; t.a = even_tex; t.b = odd_tex;
+    b->texs.push_back(t);
+    int id = (int)b->texs.size() - 1;
+    append_fmt(b->log, "tex_checker %d %d %d\n", id, even_tex, odd_tex);
+    return id;
+}
+int rt_tex_noise(rt_builder* b, double scale) {
+    if (!b) return RT_ERR_INVALID;
+    TexRec t; t.type = RT_TEX_NOISE; t.p[0] = scale;
+    // Perlin::init (perlin.rs:46-54): 256 un-normalised gradients from random_range(-1,1), then three
+    // permutations, each shuffled by `for i in 1..n { swap(p[i], p[random_int(0, n-i)]) }` (perlin.rs:28-34)
+    t.perlin_vec.resize(RT_PERLIN_POINTS * 3);
+    for (int i = 0; i < RT_PERLIN_POINTS; ++i)
+        for (int k = 0; k < 3; ++k) t.perlin_vec[(size_t)i * 3 + k] = b->rng.range(-1.0, 1.0);
+    t.perlin_perm.resize(RT_PERLIN_POINTS * 3);
+    for (int axis = 0; axis < 3; ++axis) {
+        int32_t* p = t.perlin_perm.data() + axis * RT_PERLIN_POINTS;
+        for (int i = 0; i < RT_PERLIN_POINTS; ++i) p[i] = i;
+        for (int i = 1; i < RT_PERLIN_POINTS; ++i) {
+            int target = b->rng.irange(0, RT_PERLIN_POINTS - i);
+            std::swap(p[i], p[target]);
+        }
+    }
+    b->texs.push_back(t);
+    int id = (int)b->texs.size() - 1;
+    append_fmt(b->log, "tex_noise %d %a", id, scale);
+    for (double v : b->texs.back().perlin_vec) append_fmt(b->log, " %a", v);
+    for (int32_t v : b->texs.back().perlin_perm) append_fmt(b->log, " %d", v);
+    b->log += "\n";
+    return id;
+}
+int rt_tex_image(rt_builder* b, const uint8_t* rgb8, uint32_t width, uint32_t height) {
+    if (!b) return RT_ERR_INVALID;
+    if (!rgb8 || width == 0 || height == 0) return b->fail(RT_ERR_INVALID, "image: empty");
+    TexRec t; t.type = RT_TEX_IMAGE; t.width = width; t.height = height;
+    t.texels.assign(rgb8, rgb8 + (size_t)width * height * 3);
+    b->texs.push_back(t);
+    int id = (int)b->texs.size() - 1;
+    append_fmt(b->log, "tex_image %d %u %u %zu\n", id, width, height, b->texs.back().texels.size());
+    b->log.append((const char*)rgb8, (size_t)width * height * 3);
+    b->log += "\n";
+    return id;
+}
+
+static int add_mat(rt_builder* b, uint32_t type, int tex, double p0, double p1, double p2, double p3) {
+    MatRec m; m.type = type; m.tex = tex; m.p[0] = p0; m.p[1] = p1; m.p[2] = p2; m.p[3] = p3;
+    b->mats.push_back(m);
+    return (int)b->mats.size() - 1;
+}
+int rt_mat_lambertian(rt_builder* b, int tex) {
+    if (!b) return RT_ERR_INVALID;
+    if (!b->valid_tex(tex)) return b->fail(RT_ERR_INVALID, "lambertian: bad texture handle %d", tex);
+    int id = add_mat(b, RT_MAT_LAMBERTIAN, tex, 0, 0, 0, 0);
+    append_fmt(b->log, "mat_lambertian %d %d\n", id, tex);
+    return id;
+}
+int rt_mat_metal(rt_builder* b, double r, double g, double bl, double fuzz) {
+    if (!b) return RT_ERR_INVALID;
+    double f1 = fuzz;
+    if (f1 > 1.0) f1 = 1.0; // material.rs:69-72
+    int id = add_mat(b, RT_MAT_METAL, -1, r, g, bl, f1);
+    append_fmt(b->log, "mat_metal %d %a %a %a %a\n", id, r, g, bl, fuzz);
+    return id;
+}
+int rt_mat_dielectric(rt_builder* b, double ir) {
+    if (!b) return RT_ERR_INVALID;
+    int id = add_mat(b, RT_MAT_DIELECTRIC, -1, ir, 0, 0, 0);
+    append_fmt(b->log, "mat_dielectric %d %a\n", id, ir);
+    return id;
+}
+int rt_mat_diffuse_light(rt_builder* b, int tex, double k) {
+    if (!b) return RT_ERR_INVALID;
+    if (!b->valid_tex(tex)) return b->fail(RT_ERR_INVALID, "diffuse_light: bad texture handle %d", tex);
+    int id = add_mat(b, RT_MAT_DIFFUSE_LIGHT, tex, k, 0, 0, 0);
+    append_fmt(b->log, "mat_diffuse_light %d %d %a\n", id, tex, k);
+    return id;
+}
+int rt_mat_isotropic(rt_builder* b, int tex) {
+    if (!b) return RT_ERR_INVALID;
+    if (!b->valid_tex(tex)) return b->fail(RT_ERR_INVALID, "isotropic: bad texture handle %d", tex);
+    int id = add_mat(b, RT_MAT_ISOTROPIC, tex, 0, 0, 0, 0);
+    append_fmt(b->log, "mat_isotropic %d %d\n", id, tex);
+    return id;
+}
+
+int rt_sphere(rt_builder* b, const double c[3], double radius, int mat) {
+    if (!b) return RT_ERR_INVALID;
+    if (!c || !b->valid_mat(mat)) return b->fail(RT_ERR_INVALID, "sphere: bad argument");
+    ObjRec o; o.kind = OBJ_SPHERE; o.mat = mat; o.d[0] = c[0]; o.d[1] = c[1]; o.d[2] = c[2]; o.d[3] = radius;
+    int id = b->add_obj(o);
+    append_fmt(b->log, "sphere %d %a %a %a %a %d\n", id, c[0], c[1], c[2], radius, mat);
+    return id;
+}
+int rt_moving_sphere(rt_builder* b, const double c0[3], const double c1[3], double time0, double time1, double radius,
+                     int mat) {
+    if (!b) return RT_ERR_INVALID;
+    if (!c0 || !c1 || !b->valid_mat(mat)) return b->fail(RT_ERR_INVALID, "moving_sphere: bad argument");
+    ObjRec o; o.kind = OBJ_MSPHERE; o.mat = mat;
+    for (int i = 0; i < 3; ++i) { o.d[i] = c0[i]; o.d[3 + i] = c1[i]; }
+    o.d[6] = time0; o.d[7] = time1; o.d[8] = radius;
+    int id = b->add_obj(o);
+    append_fmt(b->log, "moving_sphere %d %a %a %a %a %a %a %a %a %a %d\n", id, c0[0], c0[1], c0[2], c1[0], c1[1], c1[2],
+               time0, time1, radius, mat);
+    return id;
+}
+static int add_rect(rt_builder* b, ObjKind kind, const char* name, double a0, double a1, double b0, double b1, double k,
+                    int mat) {
+    if (!b) return RT_ERR_INVALID;
+    if (!b->valid_mat(mat)) return b->fail(RT_ERR_INVALID, "%s: bad material handle %d", name, mat);
+    ObjRec o; o.kind = kind; o.mat = mat; o.d[0] = a0; o.d[1] = a1; o.d[2] = b0; o.d[3] = b1; o.d[4] = k;
+    int id = b->add_obj(o);
+    append_fmt(b->log, "%s %d %a %a %a %a %a %d\n", name, id, a0, a1, b0, b1, k, mat);
+    return id;
+}
+int rt_xy_rect(rt_builder* b, double x0, double x1, double y0, double y1, double k, int mat) {
+    return add_rect(b, OBJ_XYRECT, "xy_rect", x0, x1, y0, y1, k, mat);
+}
+int rt_xz_rect(rt_builder* b, double x0, double x1, double z0, double z1, double k, int mat) {
+    return add_rect(b, OBJ_XZRECT, "xz_rect", x0, x1, z0, z1, k, mat);
+}
+int rt_yz_rect(rt_builder* b, double y0, double y1, double z0, double z1, double k, int mat) {
+    return add_rect(b, OBJ_YZRECT, "yz_rect", y0, y1, z0, z1, k, mat);
+}
+int rt_box(rt_builder* b, const double p0[3], const double p1[3], int mat) {
+    if (!b) return RT_ERR_INVALID;
+    if (!p0 || !p1 || !b->valid_mat(mat)) return b->fail(RT_ERR_INVALID, "box: bad argument");
+    ObjRec o; o.kind = OBJ_BOX; o.mat = mat;
+    for (int i = 0; i < 3; ++i) { o.d[i] = p0[i]; o.d[3 + i] = p1[i]; }
+    int id = b->add_obj(o);
+    append_fmt(b->log, "box %d %a %a %a %a %a %a %d\n", id, p0[0], p0[1], p0[2], p1[0], p1[1], p1[2], mat);
+    return id;
+}
+int rt_translate(rt_builder* b, int child, const double off[3]) {
+    if (!b) return RT_ERR_INVALID;
+    if (!off || !b->valid_obj(child)) return b->fail(RT_ERR_INVALID, "translate: bad argument");
+    ObjRec o; o.kind = OBJ_TRANSLATE; o.child = child; o.d[0] = off[0]; o.d[1] = off[1]; o.d[2] = off[2];
+    int id = b->add_obj(o);
+    append_fmt(b->log, "translate %d %d %a %a %a\n", id, child, off[0], off[1], off[2]);
+    return id;
+}
+int rt_rotate_y(rt_builder* b, int child, double angle) {
+    if (!b) return RT_ERR_INVALID;
+    if (!b->valid_obj(child)) return b->fail(RT_ERR_INVALID, "rotate_y: bad child handle %d", child);
+    ObjRec o; o.kind = OBJ_ROTATE_Y; o.child = child;
+    const double radians = angle * RT_PI / 180.0; // rtweekend.rs:5-7
+    o.d[0] = std::sin(radians); o.d[1] = std::cos(radians); o.d[2] = 0.0;
+    // RotateY::new (hittable.rs:104-144): bbox = the child's box at times (0,1); the rotated min/max
+    // computed at :117-141 are dropped unless the book-behaviour flag asks for them.
+    for (int i = 0; i < 3; ++i) o.box.lo[i] = o.box.hi[i] = 0.0;
+    o.hasbox = b->bounding_box(child, 0.0, 1.0, o.box);
+    if (b->flags & RT_BLOB_FLAG_BOOK_BBOX) {
+        double mn[3] = {kInf, kInf, kInf}, mx[3] = {-kInf, -kInf, -kInf};
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int k = 0; k < 2; ++k) {
+            double x = i * o.box.hi[0] + (1 - i) * o.box.lo[0];
+            double y = j * o.box.hi[1] + (1 - j) * o.box.lo[1];
+            double z = k * o.box.hi[2] + (1 - k) * o.box.lo[2];
+            double nx = o.d[1] * x + o.d[0] * z, nz = o.d[1] * z - o.d[0] * x;
+            double t[3] = {nx, y, nz};
+            for (int c = 0; c < 3; ++c) { mn[c] = rt_fmin(mn[c], t[c]); mx[c] = rt_fmax(mx[c], t[c]); }
+        }
+        for (int c = 0; c < 3; ++c) { o.box.lo[c] = mn[c]; o.box.hi[c] = mx[c]; }
+    }
+    int id = b->add_obj(o);
+    append_fmt(b->log, "rotate_y %d %d %a\n", id, child, angle);
+    return id;
+}
+int rt_constant_medium(rt_builder* b, int boundary, double density, double r, double g, double bl) {
+    if (!b) return RT_ERR_INVALID;
+    if (!b->valid_obj(boundary)) return b->fail(RT_ERR_INVALID, "constant_medium: bad boundary handle %d", boundary);
+    // ConstantMedium::new_by_color (constant_medium.rs:15-21): phase function = Isotropic(SolidColor(c))
+    TexRec t; t.type = RT_TEX_SOLID; t.p[0] = r; t.p[1] = g; t.p[2] = bl;
+    b->texs.push_back(t);
+    int mat = add_mat(b, RT_MAT_ISOTROPIC, (int)b->texs.size() - 1, 0, 0, 0, 0);
+    ObjRec o; o.kind = OBJ_MEDIUM; o.child = boundary; o.mat = mat; o.d[0] = -1.0 / density;
+    o.medium_index = b->n_media++;
+    int id = b->add_obj(o);
+    append_fmt(b->log, "constant_medium %d %d %a %a %a %a %d %d\n", id, boundary, density, r, g, bl, mat, (int)b->texs.size() - 1);
+    return id;
+}
+int rt_list_new(rt_builder* b) {
+    if (!b) return RT_ERR_INVALID;
+    ObjRec o; o.kind = OBJ_LIST;
+    int id = b->add_obj(o);
+    append_fmt(b->log, "list %d\n", id);
+    return id;
+}
+int rt_list_add(rt_builder* b, int list, int child) {
+    if (!b) return RT_ERR_INVALID;
+    if (!b->valid_obj(list) || b->objs[list].kind != OBJ_LIST || !b->valid_obj(child) || child == list)
+        return b->fail(RT_ERR_INVALID, "list_add: bad handle");
+    b->objs[list].members.push_back(child);
+    append_fmt(b->log, "list_add %d %d\n", list, child);
+    return RT_OK;
+}
+int rt_bvh(rt_builder* b, int list, double t0, double t1) {
+    if (!b) return RT_ERR_INVALID;
+    if (!b->valid_obj(list) || b->objs[list].kind != OBJ_LIST) return b->fail(RT_ERR_INVALID, "bvh: %d is not a list", list);
+    if (b->objs[list].members.empty()) return b->fail(RT_ERR_PANIC, "bvh: empty list (bvh.rs:34 would index out of bounds)");
+    std::vector<int>& objects = b->objs[list].members;
+    // comparator keys: bounding_box(0,0).min per axis (bvh.rs:73-85)
+    std::vector<double> keys(b->objs.size() * 3, 0.0);
+    for (int m : objects) {
+        AABB bb;
+        if (!b->bounding_box(m, 0.0, 0.0, bb)) return b->fail(RT_ERR_PANIC, "No bounding box");
+        for (int k = 0; k < 3; ++k) keys[(size_t)m * 3 + k] = bb.lo[k];
+    }
+    ObjRec o; o.kind = OBJ_BVH; o.child = list; o.d[0] = t0; o.d[1] = t1;
+    b->axis_log.clear();
+    if (b->build_bvh_node(o.tree, objects, keys, 0, objects.size(), t0, t1) < 0) return RT_ERR_PANIC;
+    o.box = o.tree[0].box;
+    int id = b->add_obj(std::move(o));
+    // the axes drawn (bvh.rs:22), in construction order, so that a replay can rebuild the same tree
+    append_fmt(b->log, "bvh %d %d %a %a ", id, list, t0, t1);
+    b->log += b->axis_log;
+    b->log += "\n";
+    return id;
+}
+
+int rt_builder_compile(rt_builder* b, int world, void** blob, size_t* nbytes) {
+    if (!b) return RT_ERR_INVALID;
+    b->error.clear();
+    return b->compile(world, blob, nbytes);
+}
+int rt_builder_describe(rt_builder* b, int world, char** text, size_t* nbytes) {
+    if (!b) return RT_ERR_INVALID;
+    if (!text || !nbytes || !b->valid_obj(world)) return b->fail(RT_ERR_INVALID, "describe: bad argument");
+    std::string s = b->log;
+    append_fmt(s, "world %d\n", world);
+    char* out = (char*)malloc(s.size() + 1);
+    if (!out) return b->fail(RT_ERR_OOM, "out of memory");
+    memcpy(out, s.data(), s.size());
+    out[s.size()] = 0;
+    *text = out;
+    *nbytes = s.size();
+    return RT_OK;
+}
+int rt_builder_register_image(rt_builder* b, const char* filename, const uint8_t* rgb8, uint32_t width, uint32_t height) {
+    if (!b) return RT_ERR_INVALID;
+    if (!filename || !rgb8 || !width || !height) return b->fail(RT_ERR_INVALID, "register_image: bad argument");
+    rt_builder::Image im; im.width = width; im.height = height;
+    im.rgb.assign(rgb8, rgb8 + (size_t)width * height * 3);
+    b->images[filename] = std::move(im);
+    return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,654 @@
+// Per-lane hot path: everything one path segment does, written once as host+device inline functions.
+// The HIP kernels (rt_kernels.hip) call these with an LDS-backed stack; nothing here touches wave or
+// workgroup state, so the same code can be single-stepped on a CPU by a test harness.
+//
+// Each function names the reference code it reproduces. Arithmetic is kept in the reference's
+// operation order (no reassociation, no reciprocal-multiply in place of a divide) so that results
+// match an f64 CPU evaluation bit for bit wherever only + - * / sqrt are involved.
+#pragma once
+#include "rt_math.h"
+#include "rt_types.h"
+
+#ifndef RT_INF
+#define RT_INF (__builtin_inf())
+#endif
+
+// Device-side view of an uploaded blob: typed pointers to its sections.
+struct DScene {
+    const RtNode* nodes;
+    const RtSphere* spheres;
+    const RtMeta* sphere_meta;
+    const RtMSphere* mspheres;
+    const RtMeta* msphere_meta;
+    const RtRect* rects;
+    const RtMeta* rect_meta;
+    const RtBox* boxes;
+    const RtMeta* box_meta;
+    const RtMedium* media;
+    const RtInst* insts;
+    const uint32_t* list_entries;
+    const RtMaterial* materials;
+    const RtTexture* textures;
+    const double* perlin_vec;
+    const int32_t* perlin_perm;
+    const uint8_t* texels;
+    uint32_t world;
+    uint32_t n_media;
+    uint32_t compat; // bit 0: book-correct RotateY back-rotation; bit 1: book-correct XY lens disk
+};
+#define RT_COMPAT_BOOK_ROTATE 1u
+#define RT_COMPAT_BOOK_LENS 2u
+
+// ---- instances ------------------------------------------------------------------------------------
+// Ray as the child of `inst` sees it. Translate: hittable.rs:71; RotateY: hittable.rs:149-158.
+RT_HD Ray rt_apply_inst(const RtInst& in, const Ray& r) {
+    Ray o = r;
+    if (in.op == RT_OP_TRANSLATE) {
+        o.o = r.o - v3(in.a, in.b, in.c);
+    } else {
+        const double s = in.a, c = in.b;
+        o.o.x = c * r.o.x - s * r.o.z;
+        o.o.z = s * r.o.x + c * r.o.z;
+        o.d.x = c * r.d.x - s * r.d.z;
+        o.d.z = s * r.d.x + c * r.d.z;
+    }
+    return o;
+}
+
+// The world ray carried down to the frame below instance `inst` (RT_NO_PARENT = world frame).
+RT_HD Ray rt_ray_to_level(const DScene& sc, const Ray& wray, int32_t inst) {
+    int32_t chain[RT_MAX_CHAIN];
+    int32_t p = inst;
+#pragma unroll
+    for (int k = 0; k < RT_MAX_CHAIN; ++k) {
+        chain[k] = p;
+        if (p >= 0) p = sc.insts[p].parent_inst;
+    }
+    Ray r = wray;
+#pragma unroll
+    for (int k = RT_MAX_CHAIN - 1; k >= 0; --k) {
+        if (chain[k] >= 0) r = rt_apply_inst(sc.insts[chain[k]], r);
+    }
+    return r;
+}
+
+// ---- primitive tests: return t only; the shade stage re-derives p / normal / uv from (ray, t) -------
+RT_HD V3 rt_inv_dir(const Ray& r) { return v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z); } // aabb.rs:36,49,62
+
+// AABB::hit (aabb.rs:35-75) on the node's f32 bounds widened to f64. A NaN slab product leaves the
+// interval unchanged exactly as the reference's `if t0 > t_min` selects do.
+RT_HD bool rt_aabb_hit(const RtNode& n, const Ray& r, const V3& inv, double t_min, double t_max) {
+    {
+        double t0 = ((double)n.lo[0] - r.o.x) * inv.x;
+        double t1 = ((double)n.hi[0] - r.o.x) * inv.x;
+        if (inv.x < 0.0) { double s = t0; t0 = t1; t1 = s; }
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    {
+        double t0 = ((double)n.lo[1] - r.o.y) * inv.y;
+        double t1 = ((double)n.hi[1] - r.o.y) * inv.y;
+        if (inv.y < 0.0) { double s = t0; t0 = t1; t1 = s; }
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    {
+        double t0 = ((double)n.lo[2] - r.o.z) * inv.z;
+        double t1 = ((double)n.hi[2] - r.o.z) * inv.z;
+        if (inv.z < 0.0) { double s = t0; t0 = t1; t1 = s; }
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    return true;
+}
+
+// Sphere::hit (sphere.rs:34-64): strict delta > 0 and strict t range.
+RT_HD bool rt_sphere_t(V3 center, double radius, const Ray& r, double t_min, double t_max, double& t_out) {
+    V3 oc = r.o - center;
+    double a = v3_sqlen(r.d);
+    double half_b = v3_dot(r.d, oc);
+    double c = v3_sqlen(oc) - radius * radius;
+    double delta = half_b * half_b - a * c;
+    if (delta > 0.0) {
+        double root = sqrt(delta);
+        double t = (-half_b - root) / a;
+        if (t > t_min && t < t_max) { t_out = t; return true; }
+        t = (-half_b + root) / a;
+        if (t > t_min && t < t_max) { t_out = t; return true; }
+    }
+    return false;
+}
+
+// MovingSphere::center (moving_sphere.rs:37-40)
+RT_HD V3 rt_msphere_center(const RtMSphere& s, double time) {
+    V3 c0 = v3(s.c0[0], s.c0[1], s.c0[2]), c1 = v3(s.c1[0], s.c1[1], s.c1[2]);
+    return c0 + (c1 - c0) * (time - s.t0) / (s.t1 - s.t0);
+}
+// MovingSphere::hit (moving_sphere.rs:44-69): discriminant == 0 hits, inclusive t range.
+RT_HD bool rt_msphere_t(const RtMSphere& s, const Ray& r, double t_min, double t_max, double& t_out) {
+    V3 oc = r.o - rt_msphere_center(s, r.tm);
+    double a = v3_sqlen(r.d);
+    double half_b = v3_dot(oc, r.d);
+    double c = v3_sqlen(oc) - s.r * s.r;
+    double discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.0) return false;
+    double sqrtd = sqrt(discriminant);
+    double root = (-half_b - sqrtd) / a;
+    if (root < t_min || root > t_max) {
+        root = (-half_b + sqrtd) / a;
+        if (root < t_min || root > t_max) return false;
+    }
+    t_out = root;
+    return true;
+}
+
+// One axis-aligned rectangle (arrect.rs:31-40, 83-92, 135-144). axis as in RtRect.
+RT_HD bool rt_rect_t(uint32_t axis, double a0, double a1, double b0, double b1, double k, const Ray& r,
+                     double t_min, double t_max, double& t_out) {
+    double ok, dk, oa, da, ob, db;
+    if (axis == 0u) { ok = r.o.z; dk = r.d.z; oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; }
+    else if (axis == 1u) { ok = r.o.y; dk = r.d.y; oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; }
+    else { ok = r.o.x; dk = r.d.x; oa = r.o.y; da = r.d.y; ob = r.o.z; db = r.d.z; }
+    double t = (k - ok) / dk;
+    if (t < t_min || t > t_max) return false;
+    double a = oa + t * da;
+    double b = ob + t * db;
+    if (a < a0 || a > a1 || b < b0 || b > b1) return false;
+    t_out = t;
+    return true;
+}
+
+// _Box::hit = HittableList::hit over its six sides in construction order (_box.rs:22-71,
+// hittable_list.rs:40-53): XY@z1, XY@z0, XZ@y1, XZ@y0, YZ@x1, YZ@x0, each against the shrinking
+// closest_so_far with the rects' inclusive range, so a later equal-t side wins.
+RT_HD bool rt_box_t(const RtBox& b, const Ray& r, double t_min, double t_max, double& t_out, uint32_t& face) {
+    bool hit = false;
+    double closest = t_max, t;
+    if (rt_rect_t(0u, b.p0[0], b.p1[0], b.p0[1], b.p1[1], b.p1[2], r, t_min, closest, t)) { hit = true; closest = t; face = 0u; }
+    if (rt_rect_t(0u, b.p0[0], b.p1[0], b.p0[1], b.p1[1], b.p0[2], r, t_min, closest, t)) { hit = true; closest = t; face = 1u; }
+    if (rt_rect_t(1u, b.p0[0], b.p1[0], b.p0[2], b.p1[2], b.p1[1], r, t_min, closest, t)) { hit = true; closest = t; face = 2u; }
+    if (rt_rect_t(1u, b.p0[0], b.p1[0], b.p0[2], b.p1[2], b.p0[1], r, t_min, closest, t)) { hit = true; closest = t; face = 3u; }
+    if (rt_rect_t(2u, b.p0[1], b.p1[1], b.p0[2], b.p1[2], b.p1[0], r, t_min, closest, t)) { hit = true; closest = t; face = 4u; }
+    if (rt_rect_t(2u, b.p0[1], b.p1[1], b.p0[2], b.p1[2], b.p0[0], r, t_min, closest, t)) { hit = true; closest = t; face = 5u; }
+    if (hit) t_out = closest;
+    return hit;
+}
+// The rectangle a box face stands for (same order as above).
+RT_HD RtRect rt_box_face(const RtBox& b, uint32_t face) {
+    RtRect q;
+    q.pad = 0u;
+    switch (face) {
+    case 0u: q.axis = 0u; q.a0 = b.p0[0]; q.a1 = b.p1[0]; q.b0 = b.p0[1]; q.b1 = b.p1[1]; q.k = b.p1[2]; break;
+    case 1u: q.axis = 0u; q.a0 = b.p0[0]; q.a1 = b.p1[0]; q.b0 = b.p0[1]; q.b1 = b.p1[1]; q.k = b.p0[2]; break;
+    case 2u: q.axis = 1u; q.a0 = b.p0[0]; q.a1 = b.p1[0]; q.b0 = b.p0[2]; q.b1 = b.p1[2]; q.k = b.p1[1]; break;
+    case 3u: q.axis = 1u; q.a0 = b.p0[0]; q.a1 = b.p1[0]; q.b0 = b.p0[2]; q.b1 = b.p1[2]; q.k = b.p0[1]; break;
+    case 4u: q.axis = 2u; q.a0 = b.p0[1]; q.a1 = b.p1[1]; q.b0 = b.p0[2]; q.b1 = b.p1[2]; q.k = b.p1[0]; break;
+    default: q.axis = 2u; q.a0 = b.p0[1]; q.a1 = b.p1[1]; q.b0 = b.p0[2]; q.b1 = b.p1[2]; q.k = b.p0[0]; break;
+    }
+    return q;
+}
+
+// A medium's boundary: a primitive or box, possibly under Translate/RotateY records.
+RT_HD bool rt_boundary_t(const DScene& sc, uint32_t ref, Ray r, double t_min, double t_max, double& t_out) {
+#pragma unroll 1
+    for (int guard = 0; guard <= RT_MAX_CHAIN && RT_REF_TYPE(ref) == RT_REF_INST; ++guard) {
+        const RtInst in = sc.insts[RT_REF_INDEX(ref)];
+        r = rt_apply_inst(in, r);
+        ref = in.child;
+    }
+    const uint32_t idx = RT_REF_INDEX(ref);
+    switch (RT_REF_TYPE(ref)) {
+    case RT_REF_SPHERE: {
+        const RtSphere s = sc.spheres[idx];
+        return rt_sphere_t(v3(s.cx, s.cy, s.cz), s.r, r, t_min, t_max, t_out);
+    }
+    case RT_REF_MSPHERE: return rt_msphere_t(sc.mspheres[idx], r, t_min, t_max, t_out);
+    case RT_REF_RECT: {
+        const RtRect q = sc.rects[idx];
+        return rt_rect_t(q.axis, q.a0, q.a1, q.b0, q.b1, q.k, r, t_min, t_max, t_out);
+    }
+    case RT_REF_BOX: {
+        uint32_t face;
+        return rt_box_t(sc.boxes[idx], r, t_min, t_max, t_out, face);
+    }
+    default: return false;
+    }
+}
+
+// ConstantMedium::hit (constant_medium.rs:25-66). `xi` is the uniform the reference draws at :53.
+RT_HD bool rt_medium_t(const DScene& sc, const RtMedium& m, const Ray& r, double t_min, double t_max, double xi,
+                       double& t_out) {
+    double t1, t2;
+    if (!rt_boundary_t(sc, m.boundary, r, -RT_INF, RT_INF, t1)) return false;
+    if (!rt_boundary_t(sc, m.boundary, r, t1 + 0.0001, RT_INF, t2)) return false;
+    if (t1 < t_min) t1 = t_min;
+    if (t2 > t_max) t2 = t_max;
+    if (t1 >= t2) return false;
+    if (t1 < 0.0) t1 = 0.0;
+    const double ray_length = v3_len(r.d);
+    const double distance_inside_boundary = (t2 - t1) * ray_length;
+    const double hit_distance = m.neg_inv_density * log(xi);
+    if (hit_distance > distance_inside_boundary) return false;
+    t_out = t1 + hit_distance / ray_length;
+    return true;
+}
+
+// ---- closest-hit traversal ("extend") ---------------------------------------------------------------
+// Reproduces world.hit(r, t_min, t_max, rec) (main.rs:56): HittableList::hit scans its entries in
+// order against a shrinking closest_so_far (hittable_list.rs:40-53); BvhNode::hit tests its box with
+// the current closest distance, then always left before right (bvh.rs:112-122). Because the closest
+// distance only ever shrinks along that depth-first order, the recursion equals this loop over an
+// explicit LIFO stack with one running `closest`.
+//
+// Stack: any type with push(uint32_t), pop() and empty(). XiFn: double operator()(uint32_t medium_index).
+template <class Stack, class XiFn>
+RT_HD RtHitLite rt_extend(const DScene& sc, const Ray& wray, double t_min, double t_max, Stack& st, const XiFn& xi,
+                          bool skip_media) {
+    RtHitLite best;
+    best.t = t_max;
+    best.ref = RT_REF_NONE;
+    best.aux = 0u;
+    double closest = t_max;
+    Ray r = wray;
+    V3 inv = rt_inv_dir(r);
+    st.push(sc.world);
+#pragma unroll 1
+    while (!st.empty()) {
+        const uint32_t ref = st.pop();
+        const uint32_t idx = RT_REF_INDEX(ref);
+        switch (RT_REF_TYPE(ref)) {
+        case RT_REF_NODE: {
+            const RtNode n = sc.nodes[idx];
+            if (rt_aabb_hit(n, r, inv, t_min, closest)) {
+                if (n.right != RT_REF_NONE) st.push(n.right);
+                st.push(n.left);
+            }
+            break;
+        }
+        case RT_REF_LIST: {
+            const uint32_t e = sc.list_entries[idx];
+            if (e != RT_REF_NONE) {
+                st.push(RT_MAKE_REF(RT_REF_LIST, idx + 1u));
+                st.push(e);
+            }
+            break;
+        }
+        case RT_REF_SPHERE: {
+            const RtSphere s = sc.spheres[idx];
+            double t;
+            if (rt_sphere_t(v3(s.cx, s.cy, s.cz), s.r, r, t_min, closest, t)) { closest = t; best.t = t; best.ref = ref; best.aux = 0u; }
+            break;
+        }
+        case RT_REF_MSPHERE: {
+            double t;
+            if (rt_msphere_t(sc.mspheres[idx], r, t_min, closest, t)) { closest = t; best.t = t; best.ref = ref; best.aux = 0u; }
+            break;
+        }
+        case RT_REF_RECT: {
+            const RtRect q = sc.rects[idx];
+            double t;
+            if (rt_rect_t(q.axis, q.a0, q.a1, q.b0, q.b1, q.k, r, t_min, closest, t)) { closest = t; best.t = t; best.ref = ref; best.aux = 0u; }
+            break;
+        }
+        case RT_REF_BOX: {
+            double t;
+            uint32_t face = 0u;
+            if (rt_box_t(sc.boxes[idx], r, t_min, closest, t, face)) { closest = t; best.t = t; best.ref = ref; best.aux = face; }
+            break;
+        }
+        case RT_REF_MEDIUM: {
+            if (!skip_media) {
+                const RtMedium m = sc.media[idx];
+                double t;
+                if (rt_medium_t(sc, m, r, t_min, closest, xi(m.medium_index), t)) { closest = t; best.t = t; best.ref = ref; best.aux = 0u; }
+            }
+            break;
+        }
+        case RT_REF_INST: {
+            const RtInst in = sc.insts[idx];
+            st.push(RT_MAKE_REF(RT_REF_POP, idx));
+            st.push(in.child);
+            r = rt_apply_inst(in, r);
+            inv = rt_inv_dir(r);
+            break;
+        }
+        case RT_REF_POP: {
+            r = rt_ray_to_level(sc, wray, sc.insts[idx].parent_inst);
+            inv = rt_inv_dir(r);
+            break;
+        }
+        default: break;
+        }
+    }
+    return best;
+}
+
+// ---- hit reconstruction ------------------------------------------------------------------------------
+struct HitRec {              // hittable.rs:9-18
+    V3 p, normal;
+    double t, u, v;
+    uint32_t material, src_id;
+    bool front_face;
+};
+// HitRecord::set_face_normal (hittable.rs:32-39)
+RT_HD void rt_set_face_normal(HitRec& rec, V3 dir, V3 outward) {
+    rec.front_face = v3_dot(dir, outward) < 0.0;
+    rec.normal = rec.front_face ? outward : -outward;
+}
+// Sphere::get_sphere_uv (sphere.rs:24-30)
+RT_HD void rt_sphere_uv(V3 p, double& u, double& v) {
+    double theta = acos(-p.y);
+    double phi = atan2(-p.z, p.x) + RT_PI;
+    u = phi / (2.0 * RT_PI);
+    v = theta / RT_PI;
+}
+
+// Rebuilds the HitRecord the reference's nested hit() calls would have produced for the winning
+// primitive: local hit in the primitive's frame, then each enclosing Translate (hittable.rs:75-78)
+// and RotateY (hittable.rs:164-174, including its use of the already-overwritten x) outward.
+// MovingSphere and ConstantMedium never write u,v (moving_sphere.rs:63-68, constant_medium.rs:59-65);
+// they are 0 here. `want_uv` = false skips the acos/atan2 when no texture will read them.
+RT_HD HitRec rt_reconstruct(const DScene& sc, const Ray& wray, const RtHitLite& h, bool want_uv) {
+    HitRec rec;
+    rec.t = h.t;
+    rec.u = 0.0;
+    rec.v = 0.0;
+    rec.front_face = false;
+    const uint32_t type = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
+    int32_t parent;
+    if (type == RT_REF_SPHERE) { const RtMeta m = sc.sphere_meta[idx]; rec.material = m.material; rec.src_id = m.src_id; parent = m.parent_inst; }
+    else if (type == RT_REF_MSPHERE) { const RtMeta m = sc.msphere_meta[idx]; rec.material = m.material; rec.src_id = m.src_id; parent = m.parent_inst; }
+    else if (type == RT_REF_RECT) { const RtMeta m = sc.rect_meta[idx]; rec.material = m.material; rec.src_id = m.src_id; parent = m.parent_inst; }
+    else if (type == RT_REF_BOX) { const RtMeta m = sc.box_meta[idx]; rec.material = m.material; rec.src_id = m.src_id; parent = m.parent_inst; }
+    else { const RtMedium m = sc.media[idx]; rec.material = m.material; rec.src_id = m.src_id; parent = m.parent_inst; }
+
+    int32_t chain[RT_MAX_CHAIN];
+    {
+        int32_t p = parent;
+#pragma unroll
+        for (int k = 0; k < RT_MAX_CHAIN; ++k) {
+            chain[k] = p;
+            if (p >= 0) p = sc.insts[p].parent_inst;
+        }
+    }
+    V3 dchild[RT_MAX_CHAIN]; // direction of the ray below instance chain[k]
+    Ray r = wray;
+#pragma unroll
+    for (int k = RT_MAX_CHAIN - 1; k >= 0; --k) {
+        if (chain[k] >= 0) r = rt_apply_inst(sc.insts[chain[k]], r);
+        dchild[k] = r.d;
+    }
+
+    rec.p = ray_at(r, h.t);
+    if (type == RT_REF_SPHERE) {
+        const RtSphere s = sc.spheres[idx];
+        V3 outward = (rec.p - v3(s.cx, s.cy, s.cz)) / s.r;
+        rt_set_face_normal(rec, r.d, outward);
+        if (want_uv) rt_sphere_uv(outward, rec.u, rec.v);
+    } else if (type == RT_REF_MSPHERE) {
+        const RtMSphere s = sc.mspheres[idx];
+        V3 outward = (rec.p - rt_msphere_center(s, r.tm)) / s.r;
+        rt_set_face_normal(rec, r.d, outward);
+    } else if (type == RT_REF_RECT || type == RT_REF_BOX) {
+        RtRect q;
+        if (type == RT_REF_RECT) q = sc.rects[idx]; else q = rt_box_face(sc.boxes[idx], h.aux);
+        double oa, da, ob, db;
+        V3 outward;
+        if (q.axis == 0u) { oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; outward = v3(0.0, 0.0, 1.0); }
+        else if (q.axis == 1u) { oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; outward = v3(0.0, 1.0, 0.0); }
+        else { oa = r.o.y; da = r.d.y; ob = r.o.z; db = r.d.z; outward = v3(1.0, 0.0, 0.0); }
+        double a = oa + h.t * da, b = ob + h.t * db;
+        rec.u = (a - q.a0) / (q.a1 - q.a0);   // arrect.rs:41-42
+        rec.v = (b - q.b0) / (q.b1 - q.b0);
+        rt_set_face_normal(rec, r.d, outward);
+    } else { // ConstantMedium (constant_medium.rs:62-63)
+        rec.normal = v3(1.0, 0.0, 0.0);
+        rec.front_face = true;
+    }
+
+#pragma unroll
+    for (int k = 0; k < RT_MAX_CHAIN; ++k) {
+        if (chain[k] >= 0) {
+            const RtInst in = sc.insts[chain[k]];
+            if (in.op == RT_OP_TRANSLATE) {
+                rec.p = rec.p + v3(in.a, in.b, in.c);
+                rt_set_face_normal(rec, dchild[k], rec.normal);
+            } else {
+                const double s = in.a, c = in.b;
+                V3 p_ = rec.p, n_ = rec.normal;
+                if (sc.compat & RT_COMPAT_BOOK_ROTATE) {
+                    p_.x = c * rec.p.x + s * rec.p.z;
+                    p_.z = -s * rec.p.x + c * rec.p.z;
+                    n_.x = c * rec.normal.x + s * rec.normal.z;
+                    n_.z = -s * rec.normal.x + c * rec.normal.z;
+                } else { // hittable.rs:167-171: the z lines read the x just written
+                    p_.x = c * p_.x + s * p_.z;
+                    p_.z = -s * p_.x + c * p_.z;
+                    n_.x = c * n_.x + s * n_.z;
+                    n_.z = -s * n_.x + c * n_.z;
+                }
+                rec.p = p_;
+                rt_set_face_normal(rec, dchild[k], n_);
+            }
+        }
+    }
+    return rec;
+}
+
+// ---- textures ------------------------------------------------------------------------------------------
+// Perlin::noise + trilinear_interp (perlin.rs:56-111). `tab` selects one table set.
+RT_HD double rt_perlin_noise(const DScene& sc, uint32_t tab, V3 p) {
+    const double* ranvec = sc.perlin_vec + (size_t)tab * RT_PERLIN_POINTS * 3;
+    const int32_t* perm = sc.perlin_perm + (size_t)tab * RT_PERLIN_POINTS * 3;
+    const double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
+    const double u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    const double uu = u * u * (3.0 - 2.0 * u);
+    const double vv = v * v * (3.0 - 2.0 * v);
+    const double ww = w * w * (3.0 - 2.0 * w);
+    double accum = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int ix = 255 & rt_sat_i32(fx + (double)i);
+                const int iy = 255 & rt_sat_i32(fy + (double)j);
+                const int iz = 255 & rt_sat_i32(fz + (double)k);
+                const int g = perm[ix] ^ perm[RT_PERLIN_POINTS + iy] ^ perm[2 * RT_PERLIN_POINTS + iz];
+                const V3 c = v3(ranvec[3 * g], ranvec[3 * g + 1], ranvec[3 * g + 2]);
+                const double di = (double)i, dj = (double)j, dk = (double)k;
+                const V3 weight_v = v3(u - di, v - dj, w - dk);
+                accum += (di * uu + (1.0 - di) * (1.0 - uu)) * (dj * vv + (1.0 - dj) * (1.0 - vv)) *
+                         (dk * ww + (1.0 - dk) * (1.0 - ww)) * v3_dot(c, weight_v);
+            }
+    return accum;
+}
+// Perlin::turb (perlin.rs:113-125)
+RT_HD double rt_perlin_turb(const DScene& sc, uint32_t tab, V3 p, int depth) {
+    double accum = 0.0, weight = 1.0;
+    V3 temp_p = p;
+#pragma unroll 1
+    for (int i = 0; i < depth; ++i) {
+        accum += weight * rt_perlin_noise(sc, tab, temp_p);
+        weight *= 0.5;
+        temp_p = temp_p * 2.0;
+    }
+    return fabs(accum);
+}
+// Rust `f64 as usize` (saturating, NaN -> 0), texture.rs:110-111
+RT_HD uint64_t rt_sat_usize(double v) {
+    if (!(v == v) || v <= 0.0) return 0u;
+    if (v >= 18446744073709551615.0) return UINT64_MAX;
+    return (uint64_t)v;
+}
+// Texture::value for SolidColor / CheckerTexture / NoiseTexture / ImageTexture
+// (texture.rs:23-27, 46-54, 73-79, 105-127).
+RT_HD V3 rt_tex_value(const DScene& sc, uint32_t tex, double u, double v, V3 p) {
+    RtTexture t = sc.textures[tex];
+#pragma unroll 1
+    for (int guard = 0; guard < 8 && t.type == RT_TEX_CHECKER; ++guard) {
+        double sines = sin(10.0 * p.x) * sin(10.0 * p.y) * sin(10.0 * p.z);
+        t = sc.textures[sines < 0.0 ? t.b : t.a];
+    }
+    if (t.type == RT_TEX_SOLID) return v3(t.p[0], t.p[1], t.p[2]);
+    if (t.type == RT_TEX_NOISE) {
+        double s = 0.5 * (1.0 + sin(t.p[0] * p.z + 10.0 * rt_perlin_turb(sc, t.a, p, 7)));
+        return v3(s, s, s);
+    }
+    if (t.type == RT_TEX_IMAGE) {
+        const uint64_t width = t.b, height = t.c;
+        double u_ = rt_clamp(u, 0.0, 1.0);
+        double v_ = 1.0 - rt_clamp(v, 0.0, 1.0);
+        uint64_t i = rt_sat_usize(u_ * (double)width);
+        uint64_t j = rt_sat_usize(v_ * (double)height);
+        if (i >= width) i = width - 1u;
+        if (j >= height) j = height - 1u;
+        const double color_scale = 1.0 / 255.0;
+        const uint8_t* px = sc.texels + t.a + j * (3u * width) + i * 3u;
+        return v3(color_scale * (double)px[0], color_scale * (double)px[1], color_scale * (double)px[2]);
+    }
+    return v3(0.0, 0.0, 0.0);
+}
+RT_HD bool rt_tex_reads_uv(const DScene& sc, uint32_t tex) {
+    // an image anywhere below a checker still needs uv; checkers are rare, so be conservative
+    const uint32_t ty = sc.textures[tex].type;
+    return ty == RT_TEX_IMAGE || ty == RT_TEX_CHECKER;
+}
+RT_HD bool rt_material_reads_uv(const DScene& sc, const RtMaterial& m) {
+    if (m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_ISOTROPIC || m.type == RT_MAT_DIFFUSE_LIGHT)
+        return rt_tex_reads_uv(sc, m.tex);
+    return false;
+}
+
+// ---- materials -----------------------------------------------------------------------------------------
+struct ShadeOut {
+    V3 emitted;      // Material::emitted (material.rs:19-21, 201-203)
+    V3 attenuation;
+    Ray scattered;
+    bool did_scatter;
+};
+// Dielectric::reflectance (material.rs:109-113)
+RT_HD double rt_reflectance(double cosine, double ref_idx) {
+    double r0 = (1.0 - ref_idx) / (1.0 + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.0 - r0) * rt_powi5(1.0 - cosine);
+}
+// emitted + scatter for the material of `rec`, the two calls ray_color makes at main.rs:62-66.
+RT_HD ShadeOut rt_shade(const DScene& sc, const RtMaterial& m, const Ray& r_in, const HitRec& rec, const Sampler& smp) {
+    ShadeOut o;
+    o.emitted = v3(0.0, 0.0, 0.0);
+    o.attenuation = v3(0.0, 0.0, 0.0);
+    o.scattered.o = v3(0.0, 0.0, 0.0);
+    o.scattered.d = v3(0.0, 0.0, 0.0);
+    o.scattered.tm = 0.0;
+    o.did_scatter = false;
+    switch (m.type) {
+    case RT_MAT_LAMBERTIAN: { // material.rs:41-59
+        V3 scatter_direction = rec.normal + rt_random_unit_vector(smp);
+        if (v3_near_zero(scatter_direction)) scatter_direction = rec.normal;
+        o.scattered.o = rec.p; o.scattered.d = scatter_direction; o.scattered.tm = r_in.tm;
+        o.attenuation = rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+        o.did_scatter = true;
+        break;
+    }
+    case RT_MAT_METAL: { // material.rs:80-97
+        V3 reflected = v3_reflect(v3_unit(r_in.d), rec.normal);
+        o.scattered.o = rec.p;
+        o.scattered.d = reflected + rt_random_in_unit_sphere(smp) * m.p[3];
+        o.scattered.tm = r_in.tm;
+        o.attenuation = v3(m.p[0], m.p[1], m.p[2]);
+        o.did_scatter = v3_dot(o.scattered.d, rec.normal) > 0.0;
+        break;
+    }
+    case RT_MAT_DIELECTRIC: { // material.rs:116-151
+        o.attenuation = v3(1.0, 1.0, 1.0);
+        const double ir = m.p[0];
+        double refraction_ratio = rec.front_face ? 1.0 / ir : ir;
+        V3 unit_direction = v3_unit(r_in.d);
+        double cos_theta = v3_dot(-unit_direction, rec.normal);
+        if (cos_theta > 1.0) cos_theta = 1.0;
+        double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+        bool cannot_refract = refraction_ratio * sin_theta > 1.0;
+        V3 direction;
+        if (cannot_refract || rt_reflectance(cos_theta, refraction_ratio) > sampler_draw1(smp, RT_STREAM_DIELECTRIC, 0u))
+            direction = v3_reflect(unit_direction, rec.normal);
+        else
+            direction = v3_refract(unit_direction, rec.normal, refraction_ratio);
+        o.scattered.o = rec.p; o.scattered.d = direction; o.scattered.tm = r_in.tm;
+        o.did_scatter = true;
+        break;
+    }
+    case RT_MAT_DIFFUSE_LIGHT: { // material.rs:191-204: both faces emit
+        o.emitted = rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p) * m.p[0];
+        break;
+    }
+    case RT_MAT_ISOTROPIC: { // material.rs:219-231: direction is not normalised
+        o.scattered.o = rec.p; o.scattered.d = rt_random_in_unit_sphere(smp); o.scattered.tm = r_in.tm;
+        o.attenuation = rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+        o.did_scatter = true;
+        break;
+    }
+    default: break;
+    }
+    return o;
+}
+
+// ---- camera --------------------------------------------------------------------------------------------
+// Vec3::random_in_unit_disk (vec3.rs:102-110) returns (x, 0, z); Camera::get_ray reads .x and .y
+// (camera.rs:57-58), so only the horizontal lens offset survives. Book mode samples (x, y, 0).
+RT_HD Ray rt_camera_get_ray(const RtCameraDev& cam, double s, double t, const Sampler& smp, uint32_t compat) {
+    V3 p = v3(0.0, 0.0, 0.0);
+#pragma unroll 1
+    for (uint32_t k = 0; k < RT_REJECTION_CAP; ++k) {
+        double a, b;
+        sampler_draw2(smp, RT_STREAM_LENS, k, a, b);
+        if (compat & RT_COMPAT_BOOK_LENS) p = v3(rt_range(a, -1.0, 1.0), rt_range(b, -1.0, 1.0), 0.0);
+        else p = v3(rt_range(a, -1.0, 1.0), 0.0, rt_range(b, -1.0, 1.0));
+        if (v3_sqlen(p) < 1.0) break;
+    }
+    const V3 rd = p * cam.lens_radius;
+    const V3 cu = v3(cam.u[0], cam.u[1], cam.u[2]), cv = v3(cam.v[0], cam.v[1], cam.v[2]);
+    const V3 origin = v3(cam.origin[0], cam.origin[1], cam.origin[2]);
+    const V3 llc = v3(cam.lower_left_corner[0], cam.lower_left_corner[1], cam.lower_left_corner[2]);
+    const V3 hor = v3(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
+    const V3 ver = v3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
+    const V3 offset = cu * rd.x + cv * rd.y;
+    Ray r;
+    r.o = origin + offset;
+    r.d = llc + hor * s + ver * t - origin - offset;
+    r.tm = rt_range(sampler_draw1(smp, RT_STREAM_TIME, 0u), cam.time0, cam.time1);
+    return r;
+}
+// The sample loop body up to the ray_color call (main.rs:162-164) for sample `smp.sample` of pixel (x, y).
+RT_HD Ray rt_primary_ray(const RtCameraDev& cam, uint32_t x, uint32_t y, uint32_t width, uint32_t height,
+                         const Sampler& smp, uint32_t compat) {
+    double jx, jy;
+    sampler_draw2(smp, RT_STREAM_JITTER, 0u, jx, jy);
+    const double u_ = ((double)x + jx) / ((double)width - 1.0);
+    const double v_ = ((double)y + jy) / ((double)height - 1.0);
+    return rt_camera_get_ray(cam, u_, v_, smp, compat);
+}
+// Miss colour: the constant `background` of main.rs:56-58, or (mode 1) the sky gradient the older
+// snapshot of the renderer uses (/root/reference/main.rs:59-61).
+RT_HD V3 rt_background(const double bg[3], uint32_t mode, const Ray& r) {
+    if (mode == 1u) {
+        V3 unit_direction = v3_unit(r.d);
+        double t = (unit_direction.y + 1.0) * 0.5;
+        return v3(1.0, 1.0, 1.0) * (1.0 - t) + v3(0.5, 0.7, 1.0) * t;
+    }
+    return v3(bg[0], bg[1], bg[2]);
+}
+// Final pixel conversion (main.rs:172-189)
+RT_HD uint8_t rt_tonemap_channel(double sum, double spp) {
+    double scale = 1.0 / spp;
+    double c = sqrt(scale * sum);
+    c = rt_clamp(c, 0.0, 0.999);
+    c = c * 255.999;
+    // `as i64` then `as u8`: saturating, NaN -> 0; the clamp bounds it to 0..255 already
+    int64_t q = (c == c) ? (int64_t)c : 0;
+    return (uint8_t)q;
+}

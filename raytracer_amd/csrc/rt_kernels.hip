@@ -1,0 +1,735 @@
+// gfx950 kernels of the wavefront path tracer and the device half of the C ABI (include/rt.h).
+//
+// One render pass traces S camera samples of every pixel this context owns as P = pixels * S paths that
+// advance in lock step, one bounce per iteration:
+//
+//   k_raygen                 slot = local_pixel * S + s  ->  primary ray, throughput 1, radiance 0
+//   per bounce it = 0 .. max_depth-1
+//     k_extend               closest hit of every live path (LDS stack traversal); misses are finished in
+//                            place; hits are binned by material type with wave ballots into 5 queues
+//     k_shade<material> x5   rebuild the hit record, emitted + scatter, write the next ray, and compact
+//                            surviving paths into the next iteration's queue (ballot + one atomic per wave)
+//   k_accumulate             per pixel, add its S sample radiances in sample order to the f64 sum buffer
+//
+// Path state is structure-of-arrays f64 in HBM. All queue lengths live in a device counter table that the
+// kernels read themselves, so the host never waits between launches inside a pass.
+// Random numbers are Philox keyed on (pixel, sample, bounce): results do not depend on how pixels are
+// split over GPUs or on scheduling.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt.h"
+#include "rt_builder.h"
+#include "rt_device.h"
+
+#define RT_BLOCK 256
+#define RT_COUNTER_STRIDE 8u /* per iteration: [0] live paths entering it, [1+m] hits on material type m */
+
+// ---- device structures ------------------------------------------------------------------------------------
+struct PathBufs {
+    double *ox, *oy, *oz, *dx, *dy, *dz, *tm; // current ray (ray.rs:5-9)
+    double *tr, *tg, *tb;                     // throughput: product of attenuations so far (main.rs:70)
+    double *rr, *rg, *rb;                     // radiance of the sample
+    RtHitLite* hit;
+};
+struct PassInfo {
+    const uint32_t* pixmap; // local pixel -> global pixel index y*width + x
+    uint32_t n_local, S, sample_offset, width, height, compat, bg_mode, max_depth;
+    double bg[3];
+    uint64_t seed;
+};
+struct QueueSet {
+    uint32_t* live[2];          // slot ids entering iteration it: live[it & 1]
+    uint32_t* bucket[RT_MAT_COUNT];
+    uint32_t* counters;         // (max_depth + 1) * RT_COUNTER_STRIDE
+    uint32_t* error_flag;       // bit 0: traversal stack overflow
+};
+
+struct LdsStack {
+    uint32_t* base; // this lane's column: entry k at base[k * RT_BLOCK]
+    uint32_t sp, cap;
+    uint32_t* error_flag;
+    __device__ void push(uint32_t v) {
+        if (sp < cap) { base[sp * RT_BLOCK] = v; ++sp; }
+        else if (error_flag) atomicOr(error_flag, 1u);
+    }
+    __device__ uint32_t pop() { --sp; return base[sp * RT_BLOCK]; }
+    __device__ bool empty() const { return sp == 0u; }
+};
+
+struct PhiloxXi { // the uniform a ConstantMedium draws (constant_medium.rs:53)
+    Sampler s;
+    __device__ double operator()(uint32_t medium_index) const { return sampler_draw1(s, RT_STREAM_MEDIUM0 + medium_index, 0u); }
+};
+struct ArrayXi { // injected uniforms for rt_trace_first_hit
+    const double* row;
+    __device__ double operator()(uint32_t medium_index) const { return row[medium_index]; }
+};
+
+// Appends `slot` of every lane with `take` set to queue `q`; one atomic per wave. All lanes of the wave call it.
+__device__ inline void wave_append(bool take, uint32_t slot, uint32_t* q, uint32_t* counter) {
+    const unsigned long long mask = __ballot(take);
+    if (mask == 0ull) return;
+    const uint32_t lane = __lane_id();
+    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0u;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    if (take) q[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
+}
+
+__device__ inline Ray load_ray(const PathBufs& pb, uint32_t slot) {
+    Ray r;
+    r.o = v3(pb.ox[slot], pb.oy[slot], pb.oz[slot]);
+    r.d = v3(pb.dx[slot], pb.dy[slot], pb.dz[slot]);
+    r.tm = pb.tm[slot];
+    return r;
+}
+__device__ inline Sampler slot_sampler(const PassInfo& pi, uint32_t slot, uint32_t bounce) {
+    const uint32_t lp = slot / pi.S, s = slot - lp * pi.S;
+    return sampler_make(pi.pixmap[lp], pi.sample_offset + s, bounce, pi.seed);
+}
+
+// ---- kernels ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtCameraDev cam, PassInfo pi, PathBufs pb) {
+    const uint32_t n = pi.n_local * pi.S;
+    for (uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x; slot < n; slot += gridDim.x * RT_BLOCK) {
+        const uint32_t lp = slot / pi.S, s = slot - lp * pi.S;
+        const uint32_t pixel = pi.pixmap[lp];
+        const uint32_t y = pixel / pi.width, x = pixel - y * pi.width;
+        const Sampler smp = sampler_make(pixel, pi.sample_offset + s, 0u, pi.seed);
+        const Ray r = rt_primary_ray(cam, x, y, pi.width, pi.height, smp, pi.compat);
+        pb.ox[slot] = r.o.x; pb.oy[slot] = r.o.y; pb.oz[slot] = r.o.z;
+        pb.dx[slot] = r.d.x; pb.dy[slot] = r.d.y; pb.dz[slot] = r.d.z;
+        pb.tm[slot] = r.tm;
+        pb.tr[slot] = 1.0; pb.tg[slot] = 1.0; pb.tb[slot] = 1.0;
+        pb.rr[slot] = 0.0; pb.rg[slot] = 0.0; pb.rb[slot] = 0.0;
+    }
+}
+
+// world.hit(r, 0.001, INFINITY, rec) (main.rs:56) for every live path of iteration `it`.
+__global__ void __launch_bounds__(RT_BLOCK) k_extend(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
+                                                     uint32_t stack_cap) {
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t* live = it == 0u ? nullptr : qs.live[it & 1u];
+    uint32_t* ctr = qs.counters + it * RT_COUNTER_STRIDE;
+    const uint32_t n = ctr[0];
+    LdsStack st;
+    st.base = lds_stack + threadIdx.x;
+    st.cap = stack_cap;
+    st.error_flag = qs.error_flag;
+    // whole waves iterate together so that the ballots below see every lane
+    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const bool active = i < n;
+        uint32_t slot = 0u;
+        uint32_t mat_type = 0xFFFFFFFFu;
+        if (active) {
+            slot = live ? live[i] : i;
+            const Ray r = load_ray(pb, slot);
+            PhiloxXi xi;
+            xi.s = slot_sampler(pi, slot, it);
+            st.sp = 0u;
+            const RtHitLite h = rt_extend(sc, r, 0.001, RT_INF, st, xi, false);
+            pb.hit[slot] = h;
+            if (h.ref == RT_REF_NONE) { // main.rs:56-58: return background
+                const V3 bg = rt_background(pi.bg, pi.bg_mode, r);
+                pb.rr[slot] += pb.tr[slot] * bg.x;
+                pb.rg[slot] += pb.tg[slot] * bg.y;
+                pb.rb[slot] += pb.tb[slot] * bg.z;
+            } else {
+                uint32_t m;
+                const uint32_t ty = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
+                if (ty == RT_REF_SPHERE) m = sc.sphere_meta[idx].material;
+                else if (ty == RT_REF_MSPHERE) m = sc.msphere_meta[idx].material;
+                else if (ty == RT_REF_RECT) m = sc.rect_meta[idx].material;
+                else if (ty == RT_REF_BOX) m = sc.box_meta[idx].material;
+                else m = sc.media[idx].material;
+                mat_type = sc.materials[m].type;
+            }
+        }
+#pragma unroll
+        for (uint32_t m = 0; m < RT_MAT_COUNT; ++m) wave_append(active && mat_type == m, slot, qs.bucket[m], ctr + 1u + m);
+    }
+}
+
+// emitted + scatter (main.rs:60-70) for every path of iteration `it` that hit a material of type MAT.
+template <uint32_t MAT>
+__global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it) {
+    const uint32_t* bucket = qs.bucket[MAT];
+    const uint32_t n = qs.counters[it * RT_COUNTER_STRIDE + 1u + MAT];
+    uint32_t* next = qs.live[(it + 1u) & 1u];
+    uint32_t* next_counter = qs.counters + (it + 1u) * RT_COUNTER_STRIDE;
+    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const bool active = i < n;
+        uint32_t slot = 0u;
+        bool alive = false;
+        if (active) {
+            slot = bucket[i];
+            const Ray r = load_ray(pb, slot);
+            const RtHitLite h = pb.hit[slot];
+            const uint32_t ty = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
+            uint32_t mi;
+            if (ty == RT_REF_SPHERE) mi = sc.sphere_meta[idx].material;
+            else if (ty == RT_REF_MSPHERE) mi = sc.msphere_meta[idx].material;
+            else if (ty == RT_REF_RECT) mi = sc.rect_meta[idx].material;
+            else if (ty == RT_REF_BOX) mi = sc.box_meta[idx].material;
+            else mi = sc.media[idx].material;
+            const RtMaterial m = sc.materials[mi];
+            const HitRec rec = rt_reconstruct(sc, r, h, rt_material_reads_uv(sc, m));
+            const Sampler smp = slot_sampler(pi, slot, it);
+            const ShadeOut o = rt_shade(sc, m, r, rec, smp);
+            if (MAT == RT_MAT_DIFFUSE_LIGHT) { // the only material whose emitted() is not black
+                pb.rr[slot] += pb.tr[slot] * o.emitted.x;
+                pb.rg[slot] += pb.tg[slot] * o.emitted.y;
+                pb.rb[slot] += pb.tb[slot] * o.emitted.z;
+            }
+            // a path that used its last bounce adds nothing more: ray_color(depth <= 0) is black (main.rs:52-54)
+            if (o.did_scatter && it + 1u < pi.max_depth) {
+                alive = true;
+                pb.ox[slot] = o.scattered.o.x; pb.oy[slot] = o.scattered.o.y; pb.oz[slot] = o.scattered.o.z;
+                pb.dx[slot] = o.scattered.d.x; pb.dy[slot] = o.scattered.d.y; pb.dz[slot] = o.scattered.d.z;
+                pb.tr[slot] *= o.attenuation.x; pb.tg[slot] *= o.attenuation.y; pb.tb[slot] *= o.attenuation.z;
+            }
+        }
+        wave_append(alive, slot, next, next_counter);
+    }
+}
+
+// pixel_color += ray_color(...) in sample order (main.rs:165), continuing from earlier passes.
+__global__ void __launch_bounds__(RT_BLOCK) k_accumulate(PassInfo pi, PathBufs pb, double* sum) {
+    for (uint32_t lp = blockIdx.x * RT_BLOCK + threadIdx.x; lp < pi.n_local; lp += gridDim.x * RT_BLOCK) {
+        const size_t o = (size_t)pi.pixmap[lp] * 3u;
+        double r = sum[o], g = sum[o + 1], b = sum[o + 2];
+        for (uint32_t s = 0; s < pi.S; ++s) {
+            const uint32_t slot = lp * pi.S + s;
+            r += pb.rr[slot]; g += pb.rg[slot]; b += pb.rb[slot];
+        }
+        sum[o] = r; sum[o + 1] = g; sum[o + 2] = b;
+    }
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_set_u32(uint32_t* p, uint32_t v) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *p = v;
+}
+
+// Hittable::hit of the world list for caller-supplied rays, with the full HitRecord rebuilt.
+__global__ void __launch_bounds__(RT_BLOCK) k_first_hit(DScene sc, const rt_ray_d* rays, uint32_t n, const double* xi_rows,
+                                                        rt_hit* out, uint32_t stack_cap, uint32_t* error_flag) {
+    extern __shared__ uint32_t lds_stack[];
+    LdsStack st;
+    st.base = lds_stack + threadIdx.x;
+    st.cap = stack_cap;
+    st.error_flag = error_flag;
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+        const rt_ray_d q = rays[i];
+        Ray r;
+        r.o = v3(q.ox, q.oy, q.oz); r.d = v3(q.dx, q.dy, q.dz); r.tm = q.time;
+        ArrayXi xi;
+        xi.row = xi_rows ? xi_rows + (size_t)i * sc.n_media : nullptr;
+        st.sp = 0u;
+        const RtHitLite h = rt_extend(sc, r, q.tmin, q.tmax, st, xi, xi_rows == nullptr);
+        rt_hit o;
+        memset(&o, 0, sizeof o);
+        if (h.ref == RT_REF_NONE) {
+            o.prim_id = RT_MISS;
+            o.t = q.tmax;
+        } else {
+            const HitRec rec = rt_reconstruct(sc, r, h, true);
+            o.t = rec.t;
+            o.prim_id = rec.src_id;
+            o.flags = RT_HIT_FLAG_HIT | (rec.front_face ? RT_HIT_FLAG_FRONT : 0u) | (h.aux << 4);
+            o.px = rec.p.x; o.py = rec.p.y; o.pz = rec.p.z;
+            o.nx = rec.normal.x; o.ny = rec.normal.y; o.nz = rec.normal.z;
+            o.u = rec.u; o.v = rec.v;
+            o.material_id = rec.material;
+        }
+        out[i] = o;
+    }
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_camera_rays(RtCameraDev cam, uint32_t width, uint32_t height, uint32_t sample,
+                                                          uint64_t seed, uint32_t compat, rt_ray_d* out) {
+    const uint32_t n = width * height;
+    for (uint32_t pixel = blockIdx.x * RT_BLOCK + threadIdx.x; pixel < n; pixel += gridDim.x * RT_BLOCK) {
+        const uint32_t y = pixel / width, x = pixel - y * width;
+        const Sampler smp = sampler_make(pixel, sample, 0u, seed);
+        const Ray r = rt_primary_ray(cam, x, y, width, height, smp, compat);
+        rt_ray_d o;
+        o.ox = r.o.x; o.oy = r.o.y; o.oz = r.o.z; o.dx = r.d.x; o.dy = r.d.y; o.dz = r.d.z;
+        o.time = r.tm; o.tmin = 0.001; o.tmax = RT_INF;
+        out[pixel] = o;
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------
+struct rt_scene {
+    void* d_blob = nullptr;
+    size_t nbytes = 0;
+    RtBlobHeader hdr;
+    DScene view;
+};
+
+struct rt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    int n_cu = 256;
+    // path pool
+    size_t cap_paths = 0;
+    double* f64pool = nullptr; // 13 arrays of cap_paths
+    RtHitLite* hit = nullptr;
+    uint32_t* u32pool = nullptr; // 2 live queues + 5 buckets, cap_paths each
+    uint32_t* counters = nullptr;
+    size_t cap_counters = 0;
+    uint32_t* error_flag = nullptr;
+    // pixel map cache
+    uint32_t* pixmap = nullptr;
+    uint32_t pm_w = 0, pm_h = 0, pm_tile = 0, pm_rank = 0, pm_world = 0, pm_n = 0;
+    size_t pm_cap = 0;
+    std::vector<hipEvent_t> events;
+};
+
+namespace {
+
+int ctx_fail(rt_context* c, int code, const char* what, hipError_t e = hipSuccess) {
+    if (c) {
+        c->error = what;
+        if (e != hipSuccess) { c->error += ": "; c->error += hipGetErrorString(e); }
+    }
+    return code;
+}
+#define RT_HIP(call, what)                                                   \
+    do {                                                                     \
+        hipError_t e__ = (call);                                             \
+        if (e__ != hipSuccess) return ctx_fail(ctx, e__ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_NO_DEVICE, what, e__); \
+    } while (0)
+
+int parse_header(rt_context* ctx, const RtBlobHeader& h, size_t nbytes) {
+    if (h.magic != RT_BLOB_MAGIC || h.version != RT_BLOB_VERSION) return ctx_fail(ctx, RT_ERR_INVALID, "blob: bad magic or version");
+    if (h.total_bytes != nbytes) return ctx_fail(ctx, RT_ERR_INVALID, "blob: size mismatch");
+    if (h.stack_need > RT_STACK_CAP) return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "blob: traversal stack need exceeds capacity");
+    const RtSection* secs[] = {&h.nodes, &h.spheres, &h.sphere_meta, &h.mspheres, &h.msphere_meta, &h.rects, &h.rect_meta,
+                               &h.boxes, &h.box_meta, &h.media, &h.insts, &h.list_entries, &h.materials, &h.textures,
+                               &h.perlin_vec, &h.perlin_perm, &h.texels};
+    const size_t elem[] = {sizeof(RtNode), sizeof(RtSphere), sizeof(RtMeta), sizeof(RtMSphere), sizeof(RtMeta), sizeof(RtRect),
+                           sizeof(RtMeta), sizeof(RtBox), sizeof(RtMeta), sizeof(RtMedium), sizeof(RtInst), 4, sizeof(RtMaterial),
+                           sizeof(RtTexture), 8, 4, 1};
+    for (size_t i = 0; i < sizeof(secs) / sizeof(secs[0]); ++i)
+        if (secs[i]->offset > nbytes || secs[i]->count * elem[i] > nbytes - secs[i]->offset)
+            return ctx_fail(ctx, RT_ERR_INVALID, "blob: section out of range");
+    return RT_OK;
+}
+
+void make_view(rt_scene* s) {
+    const uint8_t* b = (const uint8_t*)s->d_blob;
+    const RtBlobHeader& h = s->hdr;
+    DScene& v = s->view;
+    v.nodes = (const RtNode*)(b + h.nodes.offset);
+    v.spheres = (const RtSphere*)(b + h.spheres.offset);
+    v.sphere_meta = (const RtMeta*)(b + h.sphere_meta.offset);
+    v.mspheres = (const RtMSphere*)(b + h.mspheres.offset);
+    v.msphere_meta = (const RtMeta*)(b + h.msphere_meta.offset);
+    v.rects = (const RtRect*)(b + h.rects.offset);
+    v.rect_meta = (const RtMeta*)(b + h.rect_meta.offset);
+    v.boxes = (const RtBox*)(b + h.boxes.offset);
+    v.box_meta = (const RtMeta*)(b + h.box_meta.offset);
+    v.media = (const RtMedium*)(b + h.media.offset);
+    v.insts = (const RtInst*)(b + h.insts.offset);
+    v.list_entries = (const uint32_t*)(b + h.list_entries.offset);
+    v.materials = (const RtMaterial*)(b + h.materials.offset);
+    v.textures = (const RtTexture*)(b + h.textures.offset);
+    v.perlin_vec = (const double*)(b + h.perlin_vec.offset);
+    v.perlin_perm = (const int32_t*)(b + h.perlin_perm.offset);
+    v.texels = (const uint8_t*)(b + h.texels.offset);
+    v.world = h.world;
+    v.n_media = h.n_media;
+    v.compat = 0;
+}
+
+int ensure_paths(rt_context* ctx, size_t paths, uint32_t max_depth) {
+    if (paths > ctx->cap_paths) {
+        if (ctx->f64pool) hipFree(ctx->f64pool);
+        if (ctx->hit) hipFree(ctx->hit);
+        if (ctx->u32pool) hipFree(ctx->u32pool);
+        ctx->f64pool = nullptr; ctx->hit = nullptr; ctx->u32pool = nullptr; ctx->cap_paths = 0;
+        RT_HIP(hipMalloc((void**)&ctx->f64pool, paths * 13 * sizeof(double)), "hipMalloc path state");
+        RT_HIP(hipMalloc((void**)&ctx->hit, paths * sizeof(RtHitLite)), "hipMalloc hit records");
+        RT_HIP(hipMalloc((void**)&ctx->u32pool, paths * 7 * sizeof(uint32_t)), "hipMalloc queues");
+        ctx->cap_paths = paths;
+    }
+    const size_t need = (size_t)(max_depth + 2) * RT_COUNTER_STRIDE;
+    if (need > ctx->cap_counters) {
+        if (ctx->counters) hipFree(ctx->counters);
+        ctx->counters = nullptr; ctx->cap_counters = 0;
+        RT_HIP(hipMalloc((void**)&ctx->counters, need * sizeof(uint32_t)), "hipMalloc counters");
+        ctx->cap_counters = need;
+    }
+    return RT_OK;
+}
+
+// Pixels of the tiles this rank owns (tile k belongs to rank k % world), tile by tile, row-major inside a tile.
+int ensure_pixmap(rt_context* ctx, const rt_params* p) {
+    const uint32_t tile = p->tile ? p->tile : 32u;
+    const uint32_t world = p->tile_world ? p->tile_world : 1u;
+    const uint32_t rank = p->tile_rank;
+    if (rank >= world) return ctx_fail(ctx, RT_ERR_INVALID, "tile_rank >= tile_world");
+    if (ctx->pixmap && ctx->pm_w == p->width && ctx->pm_h == p->height && ctx->pm_tile == tile && ctx->pm_rank == rank &&
+        ctx->pm_world == world)
+        return RT_OK;
+    std::vector<uint32_t> map;
+    const uint32_t tx = (p->width + tile - 1) / tile, ty = (p->height + tile - 1) / tile;
+    for (uint32_t k = rank; k < tx * ty; k += world) {
+        const uint32_t x0 = (k % tx) * tile, y0 = (k / tx) * tile;
+        for (uint32_t y = y0; y < y0 + tile && y < p->height; ++y)
+            for (uint32_t x = x0; x < x0 + tile && x < p->width; ++x) map.push_back(y * p->width + x);
+    }
+    if (map.size() > ctx->pm_cap) {
+        if (ctx->pixmap) hipFree(ctx->pixmap);
+        ctx->pixmap = nullptr; ctx->pm_cap = 0;
+        RT_HIP(hipMalloc((void**)&ctx->pixmap, std::max<size_t>(map.size(), 1) * sizeof(uint32_t)), "hipMalloc pixel map");
+        ctx->pm_cap = map.size();
+    }
+    if (!map.empty())
+        RT_HIP(hipMemcpy(ctx->pixmap, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "upload pixel map");
+    ctx->pm_w = p->width; ctx->pm_h = p->height; ctx->pm_tile = tile; ctx->pm_rank = rank; ctx->pm_world = world;
+    ctx->pm_n = (uint32_t)map.size();
+    return RT_OK;
+}
+
+uint32_t grid_for(const rt_context* ctx, size_t items, uint32_t blocks_per_cu) {
+    const size_t want = (items + RT_BLOCK - 1) / RT_BLOCK;
+    const size_t cap = (size_t)ctx->n_cu * blocks_per_cu;
+    return (uint32_t)std::max<size_t>(1, std::min(want, cap));
+}
+
+struct EventTimer { // brackets launches with events when profiling; sums are read after the pass has drained
+    rt_context* ctx;
+    bool on;
+    size_t used = 0;
+    struct Span { size_t a, b; int kind; };
+    std::vector<Span> spans;
+    hipEvent_t get() {
+        if (used == ctx->events.size()) {
+            hipEvent_t e;
+            hipEventCreate(&e);
+            ctx->events.push_back(e);
+        }
+        return ctx->events[used++];
+    }
+    size_t begin() {
+        if (!on) return 0;
+        hipEventRecord(get(), ctx->stream);
+        return used - 1;
+    }
+    void end(size_t a, int kind) {
+        if (!on) return;
+        hipEventRecord(get(), ctx->stream);
+        spans.push_back(Span{a, used - 1, kind});
+    }
+};
+
+template <uint32_t MAT>
+void launch_shade(rt_context* ctx, const rt_scene* sc, const PassInfo& pi, const PathBufs& pb, const QueueSet& qs, uint32_t it,
+                  uint32_t grid, EventTimer& tm) {
+    size_t a = tm.begin();
+    hipLaunchKernelGGL(k_shade<MAT>, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, sc->view, pi, pb, qs, it);
+    tm.end(a, 2 + (int)MAT);
+}
+
+} // namespace
+
+extern "C" {
+
+int rt_init(rt_context** out, int device) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RT_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return RT_ERR_INVALID;
+    rt_context* ctx = new (std::nothrow) rt_context();
+    if (!ctx) return RT_ERR_OOM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return RT_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
+    if (hipMalloc((void**)&ctx->error_flag, sizeof(uint32_t)) != hipSuccess) {
+        hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return RT_ERR_OOM;
+    }
+    hipMemset(ctx->error_flag, 0, sizeof(uint32_t));
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_shutdown(rt_context* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (hipEvent_t e : ctx->events) hipEventDestroy(e);
+    if (ctx->f64pool) hipFree(ctx->f64pool);
+    if (ctx->hit) hipFree(ctx->hit);
+    if (ctx->u32pool) hipFree(ctx->u32pool);
+    if (ctx->counters) hipFree(ctx->counters);
+    if (ctx->pixmap) hipFree(ctx->pixmap);
+    if (ctx->error_flag) hipFree(ctx->error_flag);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* rt_last_error(const rt_context* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+static int upload_common(rt_context* ctx, const void* src, size_t nbytes, bool src_on_device, rt_scene** out) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!src || !out || nbytes < sizeof(RtBlobHeader)) return ctx_fail(ctx, RT_ERR_INVALID, "scene_upload: bad argument");
+    RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    rt_scene* s = new (std::nothrow) rt_scene();
+    if (!s) return ctx_fail(ctx, RT_ERR_OOM, "out of memory");
+    hipError_t e = hipMemcpy(&s->hdr, src, sizeof(RtBlobHeader), src_on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost);
+    if (e != hipSuccess) { delete s; return ctx_fail(ctx, RT_ERR_NO_DEVICE, "read blob header", e); }
+    int rc = parse_header(ctx, s->hdr, nbytes);
+    if (rc != RT_OK) { delete s; return rc; }
+    e = hipMalloc(&s->d_blob, nbytes);
+    if (e != hipSuccess) { delete s; return ctx_fail(ctx, RT_ERR_OOM, "hipMalloc scene", e); }
+    e = hipMemcpy(s->d_blob, src, nbytes, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_NO_DEVICE, "copy scene", e); }
+    s->nbytes = nbytes;
+    make_view(s);
+    *out = s;
+    return RT_OK;
+}
+int rt_scene_upload(rt_context* ctx, const void* blob, size_t nbytes, rt_scene** out) { return upload_common(ctx, blob, nbytes, false, out); }
+int rt_scene_upload_from_device(rt_context* ctx, const void* d_blob, size_t nbytes, rt_scene** out) { return upload_common(ctx, d_blob, nbytes, true, out); }
+void rt_scene_free(rt_context* ctx, rt_scene* s) {
+    if (!s) return;
+    if (ctx) hipSetDevice(ctx->device);
+    if (s->d_blob) hipFree(s->d_blob);
+    delete s;
+}
+
+static int check_error_flag(rt_context* ctx) {
+    uint32_t flag = 0;
+    RT_HIP(hipMemcpy(&flag, ctx->error_flag, sizeof flag, hipMemcpyDeviceToHost), "read error flag");
+    if (flag) {
+        hipMemset(ctx->error_flag, 0, sizeof(uint32_t));
+        return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "traversal stack overflow on device");
+    }
+    return RT_OK;
+}
+
+int rt_trace_first_hit(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays, size_t n, const double* medium_xi, rt_hit* out) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!sc || (!rays && n) || (!out && n) || n > 0x7FFFFFFFu) return ctx_fail(ctx, RT_ERR_INVALID, "trace_first_hit: bad argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    rt_ray_d* d_rays = nullptr;
+    rt_hit* d_out = nullptr;
+    double* d_xi = nullptr;
+    int rc = RT_OK;
+    const size_t xi_bytes = medium_xi ? n * (size_t)sc->hdr.n_media * sizeof(double) : 0;
+    hipError_t e = hipMalloc((void**)&d_rays, n * sizeof(rt_ray_d));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, n * sizeof(rt_hit));
+    if (e == hipSuccess && xi_bytes) e = hipMalloc((void**)&d_xi, xi_bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, n * sizeof(rt_ray_d), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && xi_bytes) e = hipMemcpyAsync(d_xi, medium_xi, xi_bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        const uint32_t cap = sc->hdr.stack_need;
+        const size_t lds = (size_t)cap * RT_BLOCK * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_first_hit, dim3(grid_for(ctx, n, 4)), dim3(RT_BLOCK), lds, ctx->stream, sc->view, d_rays, (uint32_t)n,
+                           (const double*)d_xi, d_out, cap, ctx->error_flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = ctx_fail(ctx, RT_ERR_NO_DEVICE, "trace_first_hit", e);
+    if (d_rays) hipFree(d_rays);
+    if (d_out) hipFree(d_out);
+    if (d_xi) hipFree(d_xi);
+    if (rc == RT_OK) rc = check_error_flag(ctx);
+    return rc;
+}
+
+int rt_generate_rays(rt_context* ctx, const rt_camera* cam, const rt_params* p, uint32_t sample, rt_ray_d* out) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!cam || !p || !out || p->width < 2 || p->height < 2) return ctx_fail(ctx, RT_ERR_INVALID, "generate_rays: bad argument");
+    RtCameraDev cd;
+    int rc = rt_camera_derive(cam, &cd);
+    if (rc != RT_OK) return ctx_fail(ctx, rc, "camera: the reference would panic on these arguments");
+    RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t n = (size_t)p->width * p->height;
+    rt_ray_d* d = nullptr;
+    RT_HIP(hipMalloc((void**)&d, n * sizeof(rt_ray_d)), "hipMalloc rays");
+    hipLaunchKernelGGL(k_camera_rays, dim3(grid_for(ctx, n, 8)), dim3(RT_BLOCK), 0, ctx->stream, cd, p->width, p->height, sample,
+                       p->seed, p->compat, d);
+    hipError_t e = hipMemcpyAsync(out, d, n * sizeof(rt_ray_d), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d);
+    if (e != hipSuccess) return ctx_fail(ctx, RT_ERR_NO_DEVICE, "generate_rays", e);
+    return RT_OK;
+}
+
+int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, uint32_t sample_offset,
+                         uint32_t spp, double* d_rgb_sum, rt_stats* stats) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!sc || !cam || !p || !d_rgb_sum) return ctx_fail(ctx, RT_ERR_INVALID, "render: null argument");
+    if (p->width < 2 || p->height < 2 || p->max_depth == 0 || p->max_depth > 65535u)
+        return ctx_fail(ctx, RT_ERR_INVALID, "render: width/height must be >= 2 and 1 <= max_depth <= 65535");
+    if (sc->hdr.n_media > 65535u - RT_STREAM_MEDIUM0) return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "render: too many media");
+    RtCameraDev cd;
+    int rc = rt_camera_derive(cam, &cd);
+    if (rc != RT_OK) return ctx_fail(ctx, rc, "camera: the reference would panic on these arguments");
+    RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    rc = ensure_pixmap(ctx, p);
+    if (rc != RT_OK) return rc;
+    const uint32_t n_local = ctx->pm_n;
+    if (n_local == 0 || spp == 0) return RT_OK;
+    const size_t budget = (size_t)1 << 23;
+    uint32_t S = p->spp_per_pass ? p->spp_per_pass : (uint32_t)std::max<size_t>(1, budget / n_local);
+    S = std::min(S, spp);
+    if ((size_t)n_local * S > 0x7FFFFFFFu) return ctx_fail(ctx, RT_ERR_INVALID, "render: pixels * spp_per_pass exceeds 2^31");
+    rc = ensure_paths(ctx, (size_t)n_local * S, p->max_depth);
+    if (rc != RT_OK) return rc;
+
+    PathBufs pb;
+    double** arr[13] = {&pb.ox, &pb.oy, &pb.oz, &pb.dx, &pb.dy, &pb.dz, &pb.tm, &pb.tr, &pb.tg, &pb.tb, &pb.rr, &pb.rg, &pb.rb};
+    for (int i = 0; i < 13; ++i) *arr[i] = ctx->f64pool + (size_t)i * ctx->cap_paths;
+    pb.hit = ctx->hit;
+    QueueSet qs;
+    qs.live[0] = ctx->u32pool;
+    qs.live[1] = ctx->u32pool + ctx->cap_paths;
+    for (int m = 0; m < RT_MAT_COUNT; ++m) qs.bucket[m] = ctx->u32pool + (size_t)(2 + m) * ctx->cap_paths;
+    qs.counters = ctx->counters;
+    qs.error_flag = ctx->error_flag;
+
+    rt_scene local = *sc; // per-call compat bits ride in the by-value scene view
+    local.view.compat = p->compat;
+
+    const uint32_t stack_cap = sc->hdr.stack_need;
+    const size_t lds = (size_t)stack_cap * RT_BLOCK * sizeof(uint32_t);
+    const uint32_t extend_blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));
+    const size_t n_counters = (size_t)(p->max_depth + 2) * RT_COUNTER_STRIDE;
+    std::vector<uint32_t> host_counters(n_counters);
+
+    const auto t_begin = std::chrono::steady_clock::now();
+    uint32_t done = 0;
+    while (done < spp) {
+        const uint32_t s_now = std::min(S, spp - done);
+        PassInfo pi;
+        pi.pixmap = ctx->pixmap;
+        pi.n_local = n_local; pi.S = s_now; pi.sample_offset = sample_offset + done;
+        pi.width = p->width; pi.height = p->height; pi.compat = p->compat; pi.bg_mode = p->background_mode;
+        pi.max_depth = p->max_depth;
+        pi.bg[0] = p->background[0]; pi.bg[1] = p->background[1]; pi.bg[2] = p->background[2];
+        pi.seed = p->seed;
+        const size_t paths = (size_t)n_local * s_now;
+        EventTimer tm{ctx, p->profile != 0};
+
+        RT_HIP(hipMemsetAsync(ctx->counters, 0, n_counters * sizeof(uint32_t), ctx->stream), "clear counters");
+        hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(RT_BLOCK), 0, ctx->stream, ctx->counters, (uint32_t)paths);
+        size_t a = tm.begin();
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, paths, 8)), dim3(RT_BLOCK), 0, ctx->stream, cd, pi, pb);
+        tm.end(a, 0);
+        const uint32_t g_ext = grid_for(ctx, paths, extend_blocks_per_cu);
+        const uint32_t g_sh = grid_for(ctx, paths, 8);
+        for (uint32_t it = 0; it < p->max_depth; ++it) {
+            a = tm.begin();
+            hipLaunchKernelGGL(k_extend, dim3(g_ext), dim3(RT_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it, stack_cap);
+            tm.end(a, 1);
+            launch_shade<RT_MAT_LAMBERTIAN>(ctx, &local, pi, pb, qs, it, g_sh, tm);
+            launch_shade<RT_MAT_METAL>(ctx, &local, pi, pb, qs, it, g_sh, tm);
+            launch_shade<RT_MAT_DIELECTRIC>(ctx, &local, pi, pb, qs, it, g_sh, tm);
+            launch_shade<RT_MAT_DIFFUSE_LIGHT>(ctx, &local, pi, pb, qs, it, g_sh, tm);
+            launch_shade<RT_MAT_ISOTROPIC>(ctx, &local, pi, pb, qs, it, g_sh, tm);
+        }
+        a = tm.begin();
+        hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx, n_local, 8)), dim3(RT_BLOCK), 0, ctx->stream, pi, pb, d_rgb_sum);
+        tm.end(a, 7);
+        RT_HIP(hipGetLastError(), "kernel launch");
+        RT_HIP(hipMemcpyAsync(host_counters.data(), ctx->counters, n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream),
+               "read counters");
+        RT_HIP(hipStreamSynchronize(ctx->stream), "render pass");
+        if (stats) {
+            stats->passes += 1;
+            stats->camera_samples += paths;
+            uint64_t seg = 0;
+            for (uint32_t it = 0; it < p->max_depth; ++it) seg += host_counters[(size_t)it * RT_COUNTER_STRIDE];
+            stats->ray_segments += seg;
+            stats->medium_tests += seg * sc->hdr.n_media;
+            for (const EventTimer::Span& sp : tm.spans) {
+                float ms = 0.f;
+                hipEventElapsedTime(&ms, ctx->events[sp.a], ctx->events[sp.b]);
+                if (sp.kind == 0) { stats->raygen_ms += ms; stats->raygen_launches++; }
+                else if (sp.kind == 1) { stats->extend_ms += ms; stats->extend_launches++; }
+                else if (sp.kind == 7) { stats->accumulate_ms += ms; stats->accumulate_launches++; }
+                else { stats->shade_ms[sp.kind - 2] += ms; stats->shade_launches++; }
+            }
+            if (p->profile) stats->extend_segments += seg;
+        }
+        done += s_now;
+    }
+    if (stats) stats->seconds_render += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    return check_error_flag(ctx);
+}
+
+void rt_tonemap(const double* rgb_sum, size_t n_pixels, double spp, uint8_t* rgb8_out) {
+    if (!rgb_sum || !rgb8_out) return;
+    for (size_t i = 0; i < n_pixels * 3; ++i) rgb8_out[i] = rt_tonemap_channel(rgb_sum[i], spp);
+}
+
+int rt_render(rt_context* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, uint32_t spp, double* rgb_sum_out,
+              uint8_t* rgb8_out, rt_stats* stats) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!p || !rgb_sum_out) return ctx_fail(ctx, RT_ERR_INVALID, "render: null argument");
+    RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t n = (size_t)p->width * p->height * 3;
+    double* d_sum = nullptr;
+    RT_HIP(hipMalloc((void**)&d_sum, n * sizeof(double)), "hipMalloc framebuffer");
+    hipError_t e = hipMemset(d_sum, 0, n * sizeof(double));
+    int rc = e == hipSuccess ? rt_render_accumulate(ctx, sc, cam, p, 0, spp, d_sum, stats) : ctx_fail(ctx, RT_ERR_NO_DEVICE, "memset", e);
+    if (rc == RT_OK) {
+        e = hipMemcpy(rgb_sum_out, d_sum, n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = ctx_fail(ctx, RT_ERR_NO_DEVICE, "download framebuffer", e);
+    }
+    hipFree(d_sum);
+    if (rc == RT_OK && rgb8_out) rt_tonemap(rgb_sum_out, (size_t)p->width * p->height, (double)spp, rgb8_out);
+    return rc;
+}
+
+int rt_device_alloc(rt_context* ctx, size_t nbytes, void** d_ptr) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!d_ptr) return ctx_fail(ctx, RT_ERR_INVALID, "device_alloc: null argument");
+    RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    RT_HIP(hipMalloc(d_ptr, nbytes), "hipMalloc");
+    return RT_OK;
+}
+int rt_device_free(rt_context* ctx, void* d_ptr) {
+    if (!ctx) return RT_ERR_INVALID;
+    RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    RT_HIP(hipFree(d_ptr), "hipFree");
+    return RT_OK;
+}
+int rt_device_memset(rt_context* ctx, void* d_ptr, int value, size_t nbytes) {
+    if (!ctx) return RT_ERR_INVALID;
+    RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    RT_HIP(hipMemset(d_ptr, value, nbytes), "hipMemset");
+    return RT_OK;
+}
+int rt_device_download(rt_context* ctx, void* host_dst, const void* d_src, size_t nbytes) {
+    if (!ctx) return RT_ERR_INVALID;
+    RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    RT_HIP(hipMemcpy(host_dst, d_src, nbytes, hipMemcpyDeviceToHost), "hipMemcpy");
+    return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,136 @@
+// Flat scene blob: the plain-old-data records the scene compiler emits and the HIP kernels read.
+//
+// The blob is one relocatable byte range: an RtBlobHeader followed by 256-byte-aligned sections.
+// Every cross reference is a 32-bit tagged "ref" (type in the top 4 bits, index into that type's
+// table in the low 28), never a pointer, so the same bytes can be uploaded to any device address.
+//
+// Geometry is IEEE f64 like the reference (raytracer/src/vec3.rs:5-9); only BVH node bounds are
+// stored as f32, rounded outward so that the f32 box always contains the reference's f64 box.
+#pragma once
+#include <stdint.h>
+
+#define RT_BLOB_MAGIC 0x31425452u /* "RTB1" little endian */
+#define RT_BLOB_VERSION 3u
+
+// ---- tagged references -------------------------------------------------------------------------
+enum RtRefType : uint32_t {
+    RT_REF_NONE = 0,     // list terminator / absent child
+    RT_REF_NODE = 1,     // BvhNode            (raytracer/src/bvh.rs:8-12)
+    RT_REF_SPHERE = 2,   // Sphere             (raytracer/src/sphere.rs:9-13)
+    RT_REF_MSPHERE = 3,  // MovingSphere       (raytracer/src/moving_sphere.rs:9-16)
+    RT_REF_RECT = 4,     // XYRect/XZRect/YZRect (raytracer/src/arrect.rs)
+    RT_REF_BOX = 5,      // _Box               (raytracer/src/_box.rs:8-12), six faces resolved arithmetically
+    RT_REF_MEDIUM = 6,   // ConstantMedium     (raytracer/src/constant_medium.rs:8-12)
+    RT_REF_INST = 7,     // Translate / RotateY (raytracer/src/hittable.rs:54-57,95-101)
+    RT_REF_LIST = 8,     // HittableList: index of its first entry in the NONE-terminated entry array
+    RT_REF_POP = 9       // traversal-internal marker: leave instance `index`
+};
+#define RT_REF_SHIFT 28u
+#define RT_REF_INDEX_MASK 0x0FFFFFFFu
+#define RT_MAKE_REF(type, index) ((((uint32_t)(type)) << RT_REF_SHIFT) | ((uint32_t)(index)&RT_REF_INDEX_MASK))
+#define RT_REF_TYPE(ref) ((uint32_t)(ref) >> RT_REF_SHIFT)
+#define RT_REF_INDEX(ref) ((uint32_t)(ref)&RT_REF_INDEX_MASK)
+
+#define RT_NO_PARENT (-1)
+#define RT_MAX_CHAIN 4   /* deepest Translate/RotateY nesting above any primitive */
+#define RT_STACK_CAP 40  /* per-lane traversal stack entries (LDS) */
+
+// ---- records -------------------------------------------------------------------------------------
+// 32-byte BVH node, nodes of one tree stored in depth-first pre-order (a node's left subtree follows
+// it immediately). `left`/`right` are refs: another node, or the object the reference would store
+// in that Arc. A span-1 node (bvh.rs:33-35, same object on both sides) carries right = NONE.
+struct RtNode {
+    float lo[3];
+    float hi[3];
+    uint32_t left;
+    uint32_t right;
+};
+
+// Common per-primitive bookkeeping, one per geometry record (same index).
+struct RtMeta {
+    uint32_t material;   // index into materials
+    int32_t parent_inst; // nearest enclosing Translate/RotateY record, or RT_NO_PARENT
+    uint32_t src_id;     // handle the host API returned for this object == prim_id reported in hits
+    uint32_t pad;
+};
+
+struct RtSphere { double cx, cy, cz, r; };
+struct RtMSphere { double c0[3]; double c1[3]; double t0, t1, r, pad; };
+// axis: 0 = XYRect (a=x, b=y, k on z); 1 = XZRect (a=x, b=z, k on y); 2 = YZRect (a=y, b=z, k on x)
+struct RtRect { double a0, a1, b0, b1, k; uint32_t axis; uint32_t pad; };
+struct RtBox { double p0[3]; double p1[3]; };
+struct RtMedium {
+    double neg_inv_density; // constant_medium.rs:18
+    uint32_t boundary;      // ref: primitive, box, or instance chain ending in one
+    uint32_t material;      // the Isotropic phase function
+    int32_t parent_inst;
+    uint32_t src_id;
+    uint32_t medium_index;  // selects the Philox stream of this medium's free-flight draw
+    uint32_t pad;
+};
+enum RtInstOp : uint32_t { RT_OP_TRANSLATE = 0, RT_OP_ROTATE_Y = 1 };
+struct RtInst {
+    double a, b, c;      // translate: offset xyz; rotate_y: a = sin(theta), b = cos(theta)
+    uint32_t op;
+    uint32_t child;      // ref
+    int32_t parent_inst;
+    uint32_t src_id;
+};
+
+enum RtMaterialType : uint32_t {
+    RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2, RT_MAT_DIFFUSE_LIGHT = 3,
+    RT_MAT_ISOTROPIC = 4, RT_MAT_COUNT = 5
+};
+struct RtMaterial {
+    uint32_t type;
+    uint32_t tex;     // Lambertian/Isotropic albedo, DiffuseLight emit
+    double p[4];      // Metal: albedo rgb + fuzz; Dielectric: p[0] = ir; DiffuseLight: p[0] = k
+};
+
+enum RtTextureType : uint32_t { RT_TEX_SOLID = 0, RT_TEX_CHECKER = 1, RT_TEX_NOISE = 2, RT_TEX_IMAGE = 3 };
+struct RtTexture {
+    uint32_t type;
+    uint32_t a;       // checker: even texture; noise: perlin table index; image: texel byte offset
+    uint32_t b;       // checker: odd texture;  image: width
+    uint32_t c;       // image: height
+    double p[3];      // solid: rgb; noise: p[0] = scale
+};
+
+#define RT_PERLIN_POINTS 256
+// one Perlin table = 256 gradient vectors (3 doubles each) + perm_x, perm_y, perm_z (256 int32 each)
+
+struct RtSection { uint64_t offset; uint64_t count; };
+
+struct RtBlobHeader {
+    uint32_t magic, version;
+    uint64_t total_bytes;
+    uint32_t world;          // ref of the world HittableList (main.rs:49 takes &Arc<HittableList>)
+    uint32_t n_media;        // number of ConstantMedium objects == free-flight draws per segment
+    uint32_t stack_need;     // worst-case traversal stack depth for this scene
+    uint32_t max_chain;      // deepest instance nesting
+    uint32_t flags;          // RT_BLOB_FLAG_*
+    uint32_t n_objects;      // host handles issued (prim_id range)
+    RtSection nodes, spheres, sphere_meta, mspheres, msphere_meta, rects, rect_meta, boxes, box_meta,
+        media, insts, list_entries, materials, textures, perlin_vec, perlin_perm, texels;
+};
+#define RT_BLOB_FLAG_BOOK_BBOX 1u /* RotateY stores its rotated box (book behaviour) instead of the child's */
+
+// ---- render-time records -------------------------------------------------------------------------
+// Camera in the derived form the reference's Camera struct holds (camera.rs:7-18).
+struct RtCameraDev {
+    double origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3];
+    double lens_radius, time0, time1;
+};
+
+struct RtHitLite {   // what the extend kernel writes per path: 16 bytes
+    double t;
+    uint32_t ref;    // RT_REF_NONE = miss; else SPHERE/MSPHERE/RECT/BOX/MEDIUM ref
+    uint32_t aux;    // box: face 0..5 in _box.rs:22-71 order
+};
+
+// Philox stream ids ("consumer" field of the counter)
+enum RtStream : uint32_t {
+    RT_STREAM_JITTER = 0, RT_STREAM_LENS = 1, RT_STREAM_TIME = 2, RT_STREAM_SCATTER = 3,
+    RT_STREAM_DIELECTRIC = 4, RT_STREAM_MEDIUM0 = 16
+};
+#define RT_REJECTION_CAP 4096u /* attempts before a rejection sampler gives up (probability < 1e-1000) */
