@@ -1,0 +1,167 @@
+"""The C-ABI library: it loads, exports every symbol include/rt.h declares, reports the reference's panic sites as
+error codes, and its scene compiler emits the flat layout the kernels expect. No device compute here."""
+import ctypes as C
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+import util
+from raytracer_amd import _lib, api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "rt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = declared_functions()
+    assert len(names) >= 40
+    lib = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "librt_hip.so does not export " + n
+    assert sorted(_lib.PROTOTYPES) == names, "ctypes prototypes and include/rt.h disagree"
+
+
+def test_struct_sizes_match_the_header_layout():
+    assert C.sizeof(_lib.rt_ray_d) == 72 and C.sizeof(_lib.rt_hit) == 88
+    assert C.sizeof(_lib.rt_camera) == 15 * 8
+    assert C.sizeof(_lib.rt_params) == 16 + 24 + 8 + 7 * 4 + 4
+
+
+def test_init_without_a_device_is_an_error_code_not_a_crash():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    assert _lib.lib.rt_init(C.byref(h), 0) == _lib.RT_ERR_NO_DEVICE and not h.value
+
+
+def test_reference_panic_sites_become_error_codes():
+    b = api.Builder()
+    with pytest.raises(_lib.RtError) as e:      # image::open(..).unwrap() (texture.rs:91)
+        b.named_scene("earth")
+    assert e.value.code == _lib.RT_ERR_PANIC
+    with pytest.raises(_lib.RtError) as e:      # BvhNode over an empty list indexes out of bounds (bvh.rs:34)
+        b.bvh(b.list(), 0.0, 1.0)
+    assert e.value.code == _lib.RT_ERR_PANIC
+    m = b.lambertian_color(1, 1, 1)
+    empty = b.list()
+    with pytest.raises(_lib.RtError) as e:      # "No bounding box" (bvh.rs:58,77): an empty list has none
+        b.bvh(b.list([b.sphere((0, 0, 0), 1, m), empty]), 0.0, 1.0)
+    assert e.value.code == _lib.RT_ERR_PANIC
+    s = b.sphere((0, 0, 0), 1, m)
+    for bad in (lambda: b.sphere((0, 0, 0), 1.0, 99), lambda: b.lambertian(99), lambda: b.translate(1234, (0, 0, 0)),
+                lambda: b.list_add(s, empty), lambda: b.named_scene("no_such_scene")):
+        with pytest.raises(_lib.RtError) as e:
+            bad()
+        assert e.value.code == _lib.RT_ERR_INVALID
+
+
+def test_unsupported_shapes_are_refused_at_compile_time():
+    b = api.Builder()
+    m = b.lambertian_color(1, 1, 1)
+    s = b.sphere((0, 0, 0), 1, m)
+    deep = s
+    for _ in range(5):                           # five nested transforms > RT_MAX_CHAIN
+        deep = b.translate(deep, (1, 0, 0))
+    with pytest.raises(_lib.RtError) as e:
+        b.compile(b.list([deep]))
+    assert e.value.code == _lib.RT_ERR_UNSUPPORTED
+    lst = b.list([b.sphere((3, 0, 0), 1, m), b.sphere((6, 0, 0), 1, m)])
+    med = b.constant_medium(b.bvh(lst, 0, 1), 0.1, 1, 1, 1)   # boundary that is not a primitive
+    with pytest.raises(_lib.RtError) as e:
+        b.compile(b.list([med]))
+    assert e.value.code == _lib.RT_ERR_UNSUPPORTED
+
+
+HEADER = struct.Struct("<IIQIIIIII")  # magic, version, total, world, n_media, stack_need, max_chain, flags, n_objects
+
+
+def header(blob):
+    magic, version, total, world, n_media, stack_need, max_chain, flags, n_objects = HEADER.unpack_from(blob, 0)
+    secs = np.frombuffer(blob, dtype="<u8", count=17 * 2, offset=HEADER.size).reshape(17, 2)
+    names = ["nodes", "spheres", "sphere_meta", "mspheres", "msphere_meta", "rects", "rect_meta", "boxes", "box_meta", "media",
+             "insts", "list_entries", "materials", "textures", "perlin_vec", "perlin_perm", "texels"]
+    return dict(magic=magic, version=version, total=total, world=world, n_media=n_media, stack_need=stack_need,
+                max_chain=max_chain, flags=flags, n_objects=n_objects, sections={n: tuple(map(int, s)) for n, s in zip(names, secs)})
+
+
+def test_blob_layout_of_the_book2_final_scene():
+    _, info, blob, _ = util.build_scene("final_scene")
+    h = header(blob)
+    assert h["magic"] == 0x31425452 and h["total"] == len(blob) and len(blob) % 256 == 0
+    s = h["sections"]
+    # BvhNode counts of the reference's recursion (bvh.rs:33-50): 400 boxes -> 511 nodes, 1000 spheres -> 1023
+    assert s["nodes"][1] == 511 + 1023
+    assert s["boxes"][1] == 400 and s["mspheres"][1] == 1 and s["rects"][1] == 1
+    assert s["spheres"][1] == 1000 + 5 + 2            # + the two medium boundaries (one is the shared r=70 sphere again)
+    assert s["media"][1] == 2 == h["n_media"] and s["insts"][1] == 2 and h["max_chain"] == 2
+    assert s["texels"][1] == 1024 * 512 * 3 and s["perlin_vec"][1] == 768 and s["perlin_perm"][1] == 768
+    assert all(off % 256 == 0 for off, _ in s.values())
+    assert 2 <= h["stack_need"] <= 40
+    # world list: 11 entries then the terminator
+    world_first = h["world"] & 0x0FFFFFFF
+    entries = np.frombuffer(blob, dtype="<u4", count=s["list_entries"][1], offset=s["list_entries"][0])
+    assert (h["world"] >> 28) == 8 and np.count_nonzero(entries[world_first:world_first + 11]) == 11 and entries[world_first + 11] == 0
+
+
+def test_cornell_has_seven_nodes_and_f32_bounds_contain_the_f64_boxes():
+    b, info, blob, _ = util.build_scene("cornell_box")
+    h = header(blob)
+    assert h["sections"]["nodes"][1] == 7 and h["sections"]["rects"][1] == 6 and h["sections"]["boxes"][1] == 2
+    # a BVH over known spheres: every node's f32 box must contain the exact f64 union of its subtree
+    rng = np.random.default_rng(3)
+    b = api.Builder()
+    m = b.lambertian_color(1, 1, 1)
+    c = rng.uniform(-1000, 1000, (257, 3)) + rng.uniform(0, 1e-3, (257, 3))
+    r = rng.uniform(0.1, 3.0, 257)
+    lst = b.list([b.sphere(tuple(ci), float(ri), m) for ci, ri in zip(c, r)])
+    blob = b.compile(b.list([b.bvh(lst, 0, 1)]))
+    h = header(blob)
+    off, cnt = h["sections"]["nodes"]
+    nodes = np.frombuffer(blob, dtype=np.dtype([("lo", "<f4", 3), ("hi", "<f4", 3), ("left", "<u4"), ("right", "<u4")]), count=cnt, offset=off)
+    so, sn = h["sections"]["spheres"]
+    sph = np.frombuffer(blob, dtype="<f8", count=sn * 4, offset=so).reshape(sn, 4)
+    assert cnt == 2 * 256 - 1 + 0 or cnt >= 257 // 2    # one node per internal split plus span-1/2 leaves
+
+    def bounds(ref):
+        ty, idx = ref >> 28, ref & 0x0FFFFFFF
+        if ty == 2:
+            return sph[idx, :3] - sph[idx, 3], sph[idx, :3] + sph[idx, 3]
+        assert ty == 1
+        n = nodes[idx]
+        lo, hi = bounds(int(n["left"]))
+        if n["right"]:
+            lo2, hi2 = bounds(int(n["right"]))
+            lo, hi = np.minimum(lo, lo2), np.maximum(hi, hi2)
+        assert np.all(n["lo"].astype(np.float64) <= lo) and np.all(n["hi"].astype(np.float64) >= hi)
+        # and tight: within one f32 ulp
+        assert np.all(lo - n["lo"].astype(np.float64) <= np.spacing(np.abs(n["lo"])).astype(np.float64))
+        return lo, hi
+    bounds(1 << 28)
+    # depth-first pre-order: a node's left child, when it is a node, is the next record
+    for i, n in enumerate(nodes):
+        if n["left"] >> 28 == 1:
+            assert (n["left"] & 0x0FFFFFFF) == i + 1
+
+
+def test_description_log_replays_to_the_same_scene_twice():
+    _, _, blob1, desc1 = util.build_scene("random_scene")
+    _, _, blob2, desc2 = util.build_scene("random_scene")
+    assert blob1 == blob2 and desc1 == desc2          # scene construction is deterministic in its seeds
+
+
+def test_one_million_sphere_scene_compiles():
+    b, info, blob, _ = util.build_scene("spheres_grid", n=1_000_000)
+    h = header(blob)
+    # 1,000,001 objects -> the reference's recursion yields 2^20 - 1 nodes (depth 20)
+    assert h["sections"]["nodes"][1] == 1_048_575
+    assert h["sections"]["spheres"][1] + h["sections"]["mspheres"][1] == 1_000_001
+    assert h["stack_need"] <= 40 and info.width == 3840 and info.height == 2160

@@ -1,0 +1,54 @@
+"""Committed fixtures (tests/golden/, written by tools/make_golden.py from the oracle): rays with their first hits and
+a small render per scene. On the CPU they pin the oracle and the product's device code against regressions; on the
+GPU the HIP path must reproduce them through the C ABI. The reference itself ships no vectors for this path."""
+import os
+
+import numpy as np
+import pytest
+
+import checkers as ck
+import util
+from raytracer_amd import api
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint64), np.ascontiguousarray(b).view(np.uint64))
+
+
+@pytest.mark.parametrize("name", list(util.SCENES))
+def test_oracle_and_device_code_reproduce_golden(name):
+    g = load(name)
+    _, info, blob, desc = util.build_scene(name)
+    osc = ck.OracleScene(desc, share_bvh_axes=True)
+    xi = g["xi"] if osc.n_media else None
+    hits = osc.trace_first_hit(g["rays"], xi)
+    assert np.array_equal(hits["prim_id"], g["hits"]["prim_id"]) and same_bits(hits["t"], g["hits"]["t"])
+    sim, _ = ck.hostsim_trace_first_hit(blob, g["rays"], xi)
+    assert np.array_equal(sim["prim_id"], g["hits"]["prim_id"]) and same_bits(sim["t"], g["hits"]["t"])
+    p = api.params_from_info(info, width=20, height=15, seed=util.RENDER_SEED)
+    img, st = osc.render(info.camera, p, 4, threads=2)
+    assert same_bits(img, g["image"]) and st.ray_segments == int(g["segments"])
+    sim_img, seg = ck.hostsim_render(blob, info.camera, p, 4)
+    assert seg == int(g["segments"]) and util.rel_err(sim_img, g["image"]).max() < 1e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(util.SCENES))
+def test_gpu_reproduces_golden(gpu_ctx, name):
+    g = load(name)
+    _, info, blob, _ = util.build_scene(name)
+    scene = gpu_ctx.upload(blob)
+    n_media = g["xi"].shape[1]
+    got = gpu_ctx.trace_first_hit(scene, g["rays"], g["xi"] if n_media else None)
+    rep = util.first_hit_report(got, g["hits"])
+    assert rep["prim_match"] >= 0.9999 and rep["t_rel_max"] <= 1e-5 and rep["t_bit_equal"] >= 0.98, rep
+    p = api.params_from_info(info, width=20, height=15, seed=util.RENDER_SEED)
+    img = gpu_ctx.render(scene, info.camera, p, 4)
+    assert (util.rel_err(img, g["image"]) > 1e-9).mean() <= 0.01
+    scene.close()

@@ -1,0 +1,163 @@
+"""Parity of the HIP path, called through the C ABI, against the CPU oracle. Needs an MI355X.
+
+Gate 1: on identical input rays the first-hit primitive id must match Hittable::hit of the reference's world list
+on >= 99.99 % of rays with t within 1e-5 relative. Gate 2: the converged image must match the oracle's render of
+the same seeds within the stated RMSE and 0.5 % mean luminance. Because the kernels keep the reference's f64
+operation order, the observed agreement is far tighter than those gates: identical hits except where log()
+differs by an ulp between libms, and pixel sums equal to ~1e-15 relative."""
+import numpy as np
+import pytest
+
+import checkers as ck
+import util
+from raytracer_amd import api
+
+pytestmark = pytest.mark.gpu
+MISS = 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("name", list(util.SCENES))
+def test_gate1_first_hit(gpu_ctx, name):
+    _, info, blob, desc = util.build_scene(name)
+    osc = ck.OracleScene(desc, share_bvh_axes=True)
+    scene = gpu_ctx.upload(blob)
+    p = api.params_from_info(info, width=200, height=150, seed=util.RENDER_SEED)
+    rng = np.random.default_rng(17)
+    cam = np.concatenate([gpu_ctx.generate_rays(info.camera, p, s) for s in range(2)])
+    assert cam[:200 * 150].tobytes() == ck.oracle_generate_rays(info.camera, p, 0).tobytes()   # raygen, bit for bit
+    first = osc.trace_first_hit(cam, rng.random((len(cam), osc.n_media)) if osc.n_media else None)
+    rays = util.ray_suite(cam, first, rng, n_secondary=30000)
+    assert len(rays) >= 100000
+    xi = rng.random((len(rays), osc.n_media)) if osc.n_media else None
+    want = osc.trace_first_hit(rays, xi)
+    got = gpu_ctx.trace_first_hit(scene, rays, xi)
+    rep = util.first_hit_report(got, want)
+    hit = rep["both_hit"]
+    print("\n%s: %d rays, prim match %.6f, t bit-equal %.6f, t max rel err %.3e" %
+          (name, len(rays), rep["prim_match"], rep["t_bit_equal"], rep["t_rel_max"]))
+    assert rep["prim_match"] >= 0.9999                      # gate 1
+    assert rep["t_rel_max"] <= 1e-5                         # gate 1
+    assert rep["t_bit_equal"] >= 0.98                       # what the f64 operation order actually buys
+    # the rest of the HitRecord (hittable.rs:9-18)
+    for f in ("px", "py", "pz", "nx", "ny", "nz"):
+        assert util.rel_err(got[f][hit], want[f][hit]).max() <= 1e-9, f
+    assert np.array_equal(got["flags"][hit], want["flags"][hit])
+    assert np.array_equal(got["material_id"][hit], want["material_id"][hit])
+    writes_uv = hit & ~np.isin(want["prim_id"], util.ids_without_uv(desc))
+    assert util.rel_err(got["u"][writes_uv], want["u"][writes_uv]).max() <= 1e-12
+    assert util.rel_err(got["v"][writes_uv], want["v"][writes_uv]).max() <= 1e-12
+    scene.close()
+
+
+def test_first_hit_edge_cases(gpu_ctx):
+    _, info, blob, desc = util.build_scene("cornell_smoke")
+    scene = gpu_ctx.upload(blob)
+    osc = ck.OracleScene(desc, share_bvh_axes=True)
+    assert len(gpu_ctx.trace_first_hit(scene, np.zeros(0, dtype=api.RAY_DTYPE))) == 0          # empty batch
+    # media never hit without injected uniforms; zero-length and NaN directions must not hang or fault
+    rays = util.rays_from([(278, 278, -800), (278, 278, 100), (278, 278, 100), (278, 278, 100)],
+                          [(0, 0, 1), (0, 0, 0), (np.nan, 0, 1), (0, 1e-300, 0)])
+    got = gpu_ctx.trace_first_hit(scene, rays, None)
+    want = osc.trace_first_hit(rays, None)
+    assert np.array_equal(got["prim_id"], want["prim_id"])
+    one = util.rays_from([(278, 278, -800)], [(0.1, 0.05, 1)])                                 # ragged: one ray
+    xi = np.array([[0.3, 0.7]])
+    assert np.array_equal(gpu_ctx.trace_first_hit(scene, one, xi)["prim_id"], osc.trace_first_hit(one, xi)["prim_id"])
+    scene.close()
+
+
+@pytest.mark.parametrize("name", list(util.SCENES))
+def test_render_matches_oracle_sample_for_sample(gpu_ctx, name):
+    _, info, blob, desc = util.build_scene(name)
+    osc = ck.OracleScene(desc, share_bvh_axes=True)
+    scene = gpu_ctx.upload(blob)
+    p = api.params_from_info(info, width=64, height=48, seed=util.RENDER_SEED, spp_per_pass=3)
+    stats = api.rt_stats()
+    got, rgb8 = gpu_ctx.render(scene, info.camera, p, 8, want_rgb8=True, stats=stats)          # 3 + 3 + 2 samples: ragged passes
+    want, ost = osc.render(info.camera, p, 8)
+    err = util.rel_err(got, want)
+    off = float((err > 1e-9).mean())
+    print("\n%s: segments gpu %d oracle %d, exact entries %.4f, max rel %.3e, entries off > 1e-9: %.5f" %
+          (name, stats.ray_segments, ost.ray_segments, float((got == want).mean()), err.max(), off))
+    assert stats.camera_samples == ost.camera_samples == 64 * 48 * 8
+    # identical seeds -> identical paths; a medium's log() may differ by an ulp between libms and nudge a path
+    assert abs(int(stats.ray_segments) - int(ost.ray_segments)) <= 0.002 * ost.ray_segments
+    assert off <= 0.002
+    assert abs(got.mean() / want.mean() - 1.0) <= 1e-4
+    # the 8-bit image (main.rs:172-189) agrees wherever the sums agree
+    agree = np.all(err <= 1e-9, axis=-1)
+    assert np.array_equal(rgb8[agree], ck.oracle_tonemap(want, 8)[agree])
+    scene.close()
+
+
+def test_gate2_converged_image(gpu_ctx):
+    """4096 spp on the Book-2 final scene (low resolution so the CPU oracle finishes): per-pixel RMSE of the
+    tone-mapped mean <= 0.01 and mean luminance within 0.5 %."""
+    _, info, blob, desc = util.build_scene("final_scene")
+    osc = ck.OracleScene(desc)                      # its own BVHs: an independent tree must converge to the same image
+    scene = gpu_ctx.upload(blob)
+    p = api.params_from_info(info, width=32, height=32, seed=util.RENDER_SEED)
+    spp = 4096
+    got = gpu_ctx.render(scene, info.camera, p, spp) / spp
+    want = osc.render(info.camera, p, spp)[0] / spp
+    lum_g, lum_w = util.luminance(got).mean(), util.luminance(want).mean()
+    rmse = float(np.sqrt(np.mean((np.sqrt(np.clip(got, 0, 1)) - np.sqrt(np.clip(want, 0, 1))) ** 2)))
+    print("\nfinal_scene 32x32 @ %d spp: luminance gpu %.6f oracle %.6f (ratio %.6f), rmse of sqrt-mapped mean %.3e" %
+          (spp, lum_g, lum_w, lum_g / lum_w, rmse))
+    assert abs(lum_g / lum_w - 1.0) <= 0.005
+    assert rmse <= 0.01
+    scene.close()
+
+
+def test_results_do_not_depend_on_pass_size_tiles_or_rank_count(gpu_ctx):
+    _, info, blob, _ = util.build_scene("final_scene")
+    scene = gpu_ctx.upload(blob)
+    base = dict(width=100, height=70, seed=util.RENDER_SEED)                                   # not a multiple of the tile
+    ref = gpu_ctx.render(scene, info.camera, api.params_from_info(info, spp_per_pass=5, **base), 5)
+    again = gpu_ctx.render(scene, info.camera, api.params_from_info(info, spp_per_pass=5, **base), 5)
+    assert np.array_equal(ref, again)                                                          # run to run
+    by_one = gpu_ctx.render(scene, info.camera, api.params_from_info(info, spp_per_pass=1, **base), 5)
+    assert np.array_equal(ref, by_one)                                                         # pass size
+    for world, tile in ((2, 32), (4, 16), (8, 32), (3, 8)):
+        total = np.zeros_like(ref)
+        for rank in range(world):
+            part = gpu_ctx.render(scene, info.camera, api.params_from_info(info, spp_per_pass=2, tile=tile, tile_rank=rank,
+                                                                          tile_world=world, **base), 5)
+            assert not np.any((part != 0) & (total != 0))                                      # ranks own disjoint pixels
+            total += part
+        assert np.array_equal(total, ref), (world, tile)                                       # 1 GPU == N GPUs, bit for bit
+    scene.close()
+
+
+def test_full_size_properties(gpu_ctx):
+    """800x800 Book-2 scene at the bench's pass size: things that must hold at any size."""
+    _, info, blob, _ = util.build_scene("final_scene")
+    scene = gpu_ctx.upload(blob)
+    p = api.params_from_info(info, seed=util.RENDER_SEED, spp_per_pass=4)
+    st = api.rt_stats()
+    img = gpu_ctx.render(scene, info.camera, p, 4, stats=st)
+    assert st.camera_samples == 800 * 800 * 4 and st.passes == 1
+    assert st.camera_samples <= st.ray_segments <= 50 * st.camera_samples
+    assert np.isfinite(img).all() and (img >= 0).all() and img.mean() > 0.1
+    # linearity in the sample range: samples [0,4) == [0,2) + [2,4) accumulated into one device buffer
+    import ctypes as C
+    from raytracer_amd._lib import lib
+    d = C.c_void_p()
+    n = 800 * 800 * 3 * 8
+    assert lib.rt_device_alloc(gpu_ctx._c, n, C.byref(d)) == 0
+    assert lib.rt_device_memset(gpu_ctx._c, d, 0, n) == 0
+    gpu_ctx.render_accumulate(scene, info.camera, p, 0, 2, d.value)
+    gpu_ctx.render_accumulate(scene, info.camera, p, 2, 2, d.value)
+    two = np.zeros_like(img)
+    assert lib.rt_device_download(gpu_ctx._c, two.ctypes.data, d, n) == 0
+    assert lib.rt_device_free(gpu_ctx._c, d) == 0
+    assert np.array_equal(two, img)
+    scene.close()
+
+
+def test_upload_rejects_bad_blobs(gpu_ctx):
+    from raytracer_amd._lib import RtError
+    _, info, blob, _ = util.build_scene("two_spheres")
+    for bad in (blob[:100], b"\0" * len(blob), blob[:-256]):
+        with pytest.raises(RtError):
+            gpu_ctx.upload(bad)
