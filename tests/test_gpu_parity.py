@@ -44,8 +44,9 @@ def test_gate1_first_hit(gpu_ctx, name):
     assert np.array_equal(got["flags"][hit], want["flags"][hit])
     assert np.array_equal(got["material_id"][hit], want["material_id"][hit])
     writes_uv = hit & ~np.isin(want["prim_id"], util.ids_without_uv(desc))
-    assert util.rel_err(got["u"][writes_uv], want["u"][writes_uv]).max() <= 1e-12
-    assert util.rel_err(got["v"][writes_uv], want["v"][writes_uv]).max() <= 1e-12
+    # u, v live in [0, 1] and come from acos/atan2 (sphere.rs:24-30), whose last ulp differs between libms
+    assert util.abs_err(got["u"][writes_uv], want["u"][writes_uv]).max() <= 1e-12
+    assert util.abs_err(got["v"][writes_uv], want["v"][writes_uv]).max() <= 1e-12
     scene.close()
 
 

@@ -60,6 +60,15 @@ def rel_err(got, want):
     return r
 
 
+def abs_err(got, want):
+    """Elementwise absolute error with bit-equal values (NaN == NaN, inf == inf) counted as 0."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    with np.errstate(invalid="ignore"):
+        r = np.abs(got - want)
+    r[(got == want) | (np.isnan(got) & np.isnan(want))] = 0.0
+    return r
+
+
 def first_hit_report(got, want):
     """Parity numbers for two rt_hit arrays of the same rays."""
     same_prim = got["prim_id"] == want["prim_id"]
