@@ -240,90 +240,144 @@ RT_HD bool rt_medium_t(const DScene& sc, const RtMedium& m, const Ray& r, double
 // Reproduces world.hit(r, t_min, t_max, rec) (main.rs:56): HittableList::hit scans its entries in
 // order against a shrinking closest_so_far (hittable_list.rs:40-53); BvhNode::hit tests its box with
 // the current closest distance, then always left before right (bvh.rs:112-122). Because the closest
-// distance only ever shrinks along that depth-first order, the recursion equals this loop over an
-// explicit LIFO stack with one running `closest`.
+// distance only ever shrinks along that depth-first order, the recursion equals a loop with one
+// running `best.t`.
 //
-// Stack: any type with push(uint32_t), pop() and empty(). XiFn: double operator()(uint32_t medium_index).
-template <class Stack, class XiFn>
-RT_HD RtHitLite rt_extend(const DScene& sc, const Ray& wray, double t_min, double t_max, Stack& st, const XiFn& xi,
-                          bool skip_media) {
-    RtHitLite best;
-    best.t = t_max;
-    best.ref = RT_REF_NONE;
-    best.aux = 0u;
-    double closest = t_max;
-    Ray r = wray;
-    V3 inv = rt_inv_dir(r);
-    st.push(sc.world);
-#pragma unroll 1
-    while (!st.empty()) {
-        const uint32_t ref = st.pop();
-        const uint32_t idx = RT_REF_INDEX(ref);
-        switch (RT_REF_TYPE(ref)) {
-        case RT_REF_NODE: {
-            const RtNode n = sc.nodes[idx];
-            if (rt_aabb_hit(n, r, inv, t_min, closest)) {
-                if (n.right != RT_REF_NONE) st.push(n.right);
-                st.push(n.left);
-            }
-            break;
+// Shape of the loop (chosen for 64-wide waves):
+//  * The world list is walked in lock step by every lane: its entries, and the parameters of
+//    primitives, media and instances that sit directly in it, are wave-uniform (scalar loads, no
+//    divergence, no stack).
+//  * A BvhNode entry is walked per lane with an explicit stack, as two alternating inner loops: first
+//    descend through nodes until the lane holds a non-node reference, then - once every lane of the
+//    wave has one or has run dry - test those leaves together.
+//
+// Stack: push(uint32_t), pop(), empty().  XiFn: double operator()(uint32_t medium_index).
+// RayFn: Ray operator()() returning the world-space ray (the kernels re-read it from the path buffers
+// rather than holding a second copy in registers across an instance).
+struct RtBest {
+    double t;
+    uint32_t ref, aux;
+};
+
+// One non-node reference against the ray of its frame. Returns true if it became the closest hit.
+template <class XiFn>
+RT_HD void rt_test_leaf(const DScene& sc, uint32_t ref, const Ray& r, double t_min, RtBest& best, const XiFn& xi,
+                        bool skip_media) {
+    const uint32_t idx = RT_REF_INDEX(ref);
+    double t;
+    switch (RT_REF_TYPE(ref)) {
+    case RT_REF_SPHERE: {
+        const RtSphere s = sc.spheres[idx];
+        if (rt_sphere_t(v3(s.cx, s.cy, s.cz), s.r, r, t_min, best.t, t)) { best.t = t; best.ref = ref; best.aux = 0u; }
+        break;
+    }
+    case RT_REF_MSPHERE: {
+        if (rt_msphere_t(sc.mspheres[idx], r, t_min, best.t, t)) { best.t = t; best.ref = ref; best.aux = 0u; }
+        break;
+    }
+    case RT_REF_RECT: {
+        const RtRect q = sc.rects[idx];
+        if (rt_rect_t(q.axis, q.a0, q.a1, q.b0, q.b1, q.k, r, t_min, best.t, t)) { best.t = t; best.ref = ref; best.aux = 0u; }
+        break;
+    }
+    case RT_REF_BOX: {
+        uint32_t face = 0u;
+        if (rt_box_t(sc.boxes[idx], r, t_min, best.t, t, face)) { best.t = t; best.ref = ref; best.aux = face; }
+        break;
+    }
+    case RT_REF_MEDIUM: {
+        if (!skip_media) {
+            const RtMedium m = sc.media[idx];
+            if (rt_medium_t(sc, m, r, t_min, best.t, xi(m.medium_index), t)) { best.t = t; best.ref = ref; best.aux = 0u; }
         }
-        case RT_REF_LIST: {
+        break;
+    }
+    default: break;
+    }
+}
+
+// Everything below `root` (a BvhNode, or a list / instance nested where lanes may disagree), per lane.
+// `r` is the ray of root's frame and is restored before returning.
+template <class Stack, class XiFn, class RayFn>
+RT_HD void rt_traverse(const DScene& sc, uint32_t root, Ray& r, double t_min, RtBest& best, Stack& st, const XiFn& xi,
+                       bool skip_media, const RayFn& world_ray) {
+    V3 inv = rt_inv_dir(r);
+    uint32_t cur = root;
+#pragma unroll 1
+    for (;;) {
+        // descend: box tests only
+#pragma unroll 1
+        while (RT_REF_TYPE(cur) == RT_REF_NODE) {
+            const RtNode n = sc.nodes[RT_REF_INDEX(cur)];
+            if (rt_aabb_hit(n, r, inv, t_min, best.t)) {
+                if (n.right != RT_REF_NONE) st.push(n.right);
+                cur = n.left;
+            } else {
+                cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop();
+            }
+        }
+        if (cur == RT_REF_NONE) break;
+        const uint32_t idx = RT_REF_INDEX(cur);
+        switch (RT_REF_TYPE(cur)) {
+        case RT_REF_LIST: { // a HittableList below a BVH or instance: entries in order
             const uint32_t e = sc.list_entries[idx];
             if (e != RT_REF_NONE) {
                 st.push(RT_MAKE_REF(RT_REF_LIST, idx + 1u));
-                st.push(e);
-            }
-            break;
-        }
-        case RT_REF_SPHERE: {
-            const RtSphere s = sc.spheres[idx];
-            double t;
-            if (rt_sphere_t(v3(s.cx, s.cy, s.cz), s.r, r, t_min, closest, t)) { closest = t; best.t = t; best.ref = ref; best.aux = 0u; }
-            break;
-        }
-        case RT_REF_MSPHERE: {
-            double t;
-            if (rt_msphere_t(sc.mspheres[idx], r, t_min, closest, t)) { closest = t; best.t = t; best.ref = ref; best.aux = 0u; }
-            break;
-        }
-        case RT_REF_RECT: {
-            const RtRect q = sc.rects[idx];
-            double t;
-            if (rt_rect_t(q.axis, q.a0, q.a1, q.b0, q.b1, q.k, r, t_min, closest, t)) { closest = t; best.t = t; best.ref = ref; best.aux = 0u; }
-            break;
-        }
-        case RT_REF_BOX: {
-            double t;
-            uint32_t face = 0u;
-            if (rt_box_t(sc.boxes[idx], r, t_min, closest, t, face)) { closest = t; best.t = t; best.ref = ref; best.aux = face; }
-            break;
-        }
-        case RT_REF_MEDIUM: {
-            if (!skip_media) {
-                const RtMedium m = sc.media[idx];
-                double t;
-                if (rt_medium_t(sc, m, r, t_min, closest, xi(m.medium_index), t)) { closest = t; best.t = t; best.ref = ref; best.aux = 0u; }
+                cur = e;
+                continue;
             }
             break;
         }
         case RT_REF_INST: {
             const RtInst in = sc.insts[idx];
             st.push(RT_MAKE_REF(RT_REF_POP, idx));
-            st.push(in.child);
             r = rt_apply_inst(in, r);
             inv = rt_inv_dir(r);
-            break;
+            cur = in.child;
+            continue;
         }
-        case RT_REF_POP: {
-            r = rt_ray_to_level(sc, wray, sc.insts[idx].parent_inst);
+        case RT_REF_POP: { // leave instance idx: back to the ray of its own frame
+            r = rt_ray_to_level(sc, world_ray(), sc.insts[idx].parent_inst);
             inv = rt_inv_dir(r);
             break;
         }
-        default: break;
+        default: rt_test_leaf(sc, cur, r, t_min, best, xi, skip_media); break;
         }
+        cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop();
     }
-    return best;
+}
+
+template <class Stack, class XiFn, class RayFn>
+RT_HD RtHitLite rt_extend(const DScene& sc, const RayFn& world_ray, double t_min, double t_max, Stack& st, const XiFn& xi,
+                          bool skip_media) {
+    RtBest best;
+    best.t = t_max;
+    best.ref = RT_REF_NONE;
+    best.aux = 0u;
+    Ray r = world_ray();
+#pragma unroll 1
+    for (uint32_t li = RT_REF_INDEX(sc.world);; ++li) {
+        uint32_t e = sc.list_entries[li];
+        if (e == RT_REF_NONE) break;
+        // Translate / RotateY wrapped around the whole entry: the same for every lane
+        bool moved = false;
+#pragma unroll 1
+        while (RT_REF_TYPE(e) == RT_REF_INST) {
+            const RtInst in = sc.insts[RT_REF_INDEX(e)];
+            r = rt_apply_inst(in, r);
+            e = in.child;
+            moved = true;
+        }
+        const uint32_t ty = RT_REF_TYPE(e);
+        if (ty == RT_REF_NODE || ty == RT_REF_LIST) rt_traverse(sc, e, r, t_min, best, st, xi, skip_media, world_ray);
+        else rt_test_leaf(sc, e, r, t_min, best, xi, skip_media);
+        if (moved) r = world_ray();
+    }
+    RtHitLite h;
+    h.t = best.t;
+    h.ref = best.ref;
+    h.aux = best.aux;
+    return h;
 }
 
 // ---- hit reconstruction ------------------------------------------------------------------------------

@@ -91,6 +91,19 @@ __device__ inline Ray load_ray(const PathBufs& pb, uint32_t slot) {
     r.tm = pb.tm[slot];
     return r;
 }
+struct SlotRay { // the world-space ray of a path, re-read from the path buffers on demand
+    const PathBufs* pb;
+    uint32_t slot;
+    __device__ Ray operator()() const { return load_ray(*pb, slot); }
+};
+struct QueryRay {
+    const rt_ray_d* q;
+    __device__ Ray operator()() const {
+        Ray r;
+        r.o = v3(q->ox, q->oy, q->oz); r.d = v3(q->dx, q->dy, q->dz); r.tm = q->time;
+        return r;
+    }
+};
 __device__ inline Sampler slot_sampler(const PassInfo& pi, uint32_t slot, uint32_t bounce) {
     const uint32_t lp = slot / pi.S, s = slot - lp * pi.S;
     return sampler_make(pi.pixmap[lp], pi.sample_offset + s, bounce, pi.seed);
@@ -132,14 +145,15 @@ __global__ void __launch_bounds__(RT_BLOCK) k_extend(DScene sc, PassInfo pi, Pat
         uint32_t mat_type = 0xFFFFFFFFu;
         if (active) {
             slot = live ? live[i] : i;
-            const Ray r = load_ray(pb, slot);
+            SlotRay ray_of;
+            ray_of.pb = &pb; ray_of.slot = slot;
             PhiloxXi xi;
             xi.s = slot_sampler(pi, slot, it);
             st.sp = 0u;
-            const RtHitLite h = rt_extend(sc, r, 0.001, RT_INF, st, xi, false);
+            const RtHitLite h = rt_extend(sc, ray_of, 0.001, RT_INF, st, xi, false);
             pb.hit[slot] = h;
             if (h.ref == RT_REF_NONE) { // main.rs:56-58: return background
-                const V3 bg = rt_background(pi.bg, pi.bg_mode, r);
+                const V3 bg = rt_background(pi.bg, pi.bg_mode, ray_of());
                 pb.rr[slot] += pb.tr[slot] * bg.x;
                 pb.rg[slot] += pb.tg[slot] * bg.y;
                 pb.rb[slot] += pb.tb[slot] * bg.z;
@@ -230,12 +244,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_first_hit(DScene sc, const rt_ray_
     st.error_flag = error_flag;
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         const rt_ray_d q = rays[i];
-        Ray r;
-        r.o = v3(q.ox, q.oy, q.oz); r.d = v3(q.dx, q.dy, q.dz); r.tm = q.time;
+        QueryRay ray_of;
+        ray_of.q = rays + i;
+        const Ray r = ray_of();
         ArrayXi xi;
         xi.row = xi_rows ? xi_rows + (size_t)i * sc.n_media : nullptr;
         st.sp = 0u;
-        const RtHitLite h = rt_extend(sc, r, q.tmin, q.tmax, st, xi, xi_rows == nullptr);
+        const RtHitLite h = rt_extend(sc, ray_of, q.tmin, q.tmax, st, xi, xi_rows == nullptr);
         rt_hit o;
         memset(&o, 0, sizeof o);
         if (h.ref == RT_REF_NONE) {

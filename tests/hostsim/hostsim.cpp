@@ -23,6 +23,10 @@ struct VecStack {
     uint32_t pop() { return v[--sp]; }
     bool empty() const { return sp == 0; }
 };
+struct HeldRay {
+    Ray r;
+    Ray operator()() const { return r; }
+};
 struct PhiloxXi {
     Sampler s;
     double operator()(uint32_t m) const { return sampler_draw1(s, RT_STREAM_MEDIUM0 + m, 0u); }
@@ -87,7 +91,9 @@ int hs_trace_first_hit(const void* blob, size_t nbytes, const rt_ray_d* rays, si
         VecStack st;
         ArrayXi xi;
         xi.row = xi_rows ? xi_rows + i * sc.n_media : nullptr;
-        const RtHitLite hl = rt_extend(sc, r, rays[i].tmin, rays[i].tmax, st, xi, xi_rows == nullptr);
+        HeldRay held;
+        held.r = r;
+        const RtHitLite hl = rt_extend(sc, held, rays[i].tmin, rays[i].tmax, st, xi, xi_rows == nullptr);
         if (st.overflow) return RT_ERR_UNSUPPORTED;
         if (st.high > high) high = st.high;
         rt_hit o;
@@ -134,7 +140,9 @@ static V3 sample_radiance(const DScene& sc, const RtCameraDev& cd, const rt_para
         PhiloxXi xi;
         xi.s = smp;
         if (segments) ++*segments;
-        const RtHitLite h = rt_extend(sc, r, 0.001, RT_INF, st, xi, false);
+        HeldRay held;
+        held.r = r;
+        const RtHitLite h = rt_extend(sc, held, 0.001, RT_INF, st, xi, false);
         if (h.ref == RT_REF_NONE) {
             const V3 bg = rt_background(p->background, p->background_mode, r);
             rad.x += thr.x * bg.x; rad.y += thr.y * bg.y; rad.z += thr.z * bg.z;
