@@ -361,6 +361,21 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         wref = RT_MAKE_REF(RT_REF_LIST, first);
     }
     if (wref == RT_REF_NONE) return error.empty() ? fail(RT_ERR_UNSUPPORTED, "empty scene") : RT_ERR_UNSUPPORTED;
+    // The closest hit does not depend on the order in which the world's entries are tested (only exact ties do), so the
+    // kernels test the entries that are plain primitives or media first, in lock step, and then walk the rest per lane.
+    std::vector<uint32_t> flat_refs, tree_refs;
+    for (uint32_t i = RT_REF_INDEX(wref); f.list_entries[i] != RT_REF_NONE; ++i) {
+        uint32_t e = f.list_entries[i], leaf = e;
+        while (RT_REF_TYPE(leaf) == RT_REF_INST) leaf = f.insts[RT_REF_INDEX(leaf)].child;
+        const uint32_t ty = RT_REF_TYPE(leaf);
+        (ty == RT_REF_NODE || ty == RT_REF_LIST ? tree_refs : flat_refs).push_back(e);
+    }
+    const uint32_t flat_first = (uint32_t)f.list_entries.size();
+    for (uint32_t r : flat_refs) f.list_entries.push_back(r);
+    f.list_entries.push_back(RT_REF_NONE);
+    const uint32_t tree_first = (uint32_t)f.list_entries.size();
+    for (uint32_t r : tree_refs) f.list_entries.push_back(r);
+    f.list_entries.push_back(RT_REF_NONE);
     const uint32_t stack_need = std::max(1u, need) + 1u;
     if (stack_need > RT_STACK_CAP)
         return fail(RT_ERR_UNSUPPORTED, "scene needs a traversal stack of %u entries, capacity is %u", stack_need, RT_STACK_CAP);
@@ -420,6 +435,8 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     hd.magic = RT_BLOB_MAGIC; hd.version = RT_BLOB_VERSION;
     hd.total_bytes = blob.size();
     hd.world = wref;
+    hd.world_flat = RT_MAKE_REF(RT_REF_LIST, flat_first);
+    hd.world_tree = RT_MAKE_REF(RT_REF_LIST, tree_first);
     hd.n_media = (uint32_t)n_media;
     hd.stack_need = stack_need;
     hd.max_chain = f.max_chain;

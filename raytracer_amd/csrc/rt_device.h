@@ -32,7 +32,7 @@ struct DScene {
     const double* perlin_vec;
     const int32_t* perlin_perm;
     const uint8_t* texels;
-    uint32_t world;
+    uint32_t world, world_flat, world_tree;
     uint32_t n_media;
     uint32_t compat; // bit 0: book-correct RotateY back-rotation; bit 1: book-correct XY lens disk
 };
@@ -243,13 +243,13 @@ RT_HD bool rt_medium_t(const DScene& sc, const RtMedium& m, const Ray& r, double
 // distance only ever shrinks along that depth-first order, the recursion equals a loop with one
 // running `best.t`.
 //
-// Shape of the loop (chosen for 64-wide waves):
-//  * The world list is walked in lock step by every lane: its entries, and the parameters of
-//    primitives, media and instances that sit directly in it, are wave-uniform (scalar loads, no
-//    divergence, no stack).
-//  * A BvhNode entry is walked per lane with an explicit stack, as two alternating inner loops: first
-//    descend through nodes until the lane holds a non-node reference, then - once every lane of the
-//    wave has one or has run dry - test those leaves together.
+// Shape of the loop (chosen for 64-wide waves). The closest hit does not depend on the order in which
+// the world's entries are tested - only the winner of an exact tie does - so:
+//  * the entries that are a primitive or medium are tested first, by every lane in lock step: entry
+//    and parameters are wave-uniform (scalar loads, no divergence, no stack);
+//  * the remaining entries (BvhNode, nested lists) are walked per lane with an explicit stack, in the
+//    reference's order, as two alternating steps: descend through nodes until the lane holds a
+//    non-node reference, then test that reference.
 //
 // Stack: push(uint32_t), pop(), empty().  XiFn: double operator()(uint32_t medium_index).
 // RayFn: Ray operator()() returning the world-space ray (the kernels re-read it from the path buffers
@@ -296,54 +296,104 @@ RT_HD void rt_test_leaf(const DScene& sc, uint32_t ref, const Ray& r, double t_m
     }
 }
 
-// Everything below `root` (a BvhNode, or a list / instance nested where lanes may disagree), per lane.
-// `r` is the ray of root's frame and is restored before returning.
+// Per-lane traversal state and its two step functions. A caller alternates rt_trav_descend (box tests only,
+// until the lane holds something that is not a node) and rt_trav_visit (one non-node reference) until
+// s.cur == RT_REF_NONE. Written as steps so that a kernel can interleave them with its own wave-level work
+// (handing finished lanes a new ray) while the straight-line rt_traverse below just loops.
+struct RtTrav {
+    Ray r;        // ray of the current frame
+    V3 inv;       // 1 / r.d
+    RtBest best;  // closest hit so far; best.t doubles as the reference's shrinking t_max
+    uint32_t cur; // next reference to process; RT_REF_NONE = finished
+};
+
+// One box test: s.cur must be a node. BvhNode::hit (bvh.rs:112-122): box against the current closest distance,
+// then the left child, the right one kept for later.
+template <class Stack>
+RT_HD void rt_trav_node_step(const DScene& sc, RtTrav& s, Stack& st, double t_min) {
+    const RtNode n = sc.nodes[RT_REF_INDEX(s.cur)];
+    if (rt_aabb_hit(n, s.r, s.inv, t_min, s.best.t)) {
+        if (n.right != RT_REF_NONE) st.push(n.right);
+        s.cur = n.left;
+    } else {
+        s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop();
+    }
+}
+template <class Stack>
+RT_HD void rt_trav_descend(const DScene& sc, RtTrav& s, Stack& st, double t_min) {
+#pragma unroll 1
+    while (RT_REF_TYPE(s.cur) == RT_REF_NODE) rt_trav_node_step(sc, s, st, t_min);
+}
+
 template <class Stack, class XiFn, class RayFn>
-RT_HD void rt_traverse(const DScene& sc, uint32_t root, Ray& r, double t_min, RtBest& best, Stack& st, const XiFn& xi,
+RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, const XiFn& xi, bool skip_media,
+                         const RayFn& world_ray) {
+    const uint32_t idx = RT_REF_INDEX(s.cur);
+    switch (RT_REF_TYPE(s.cur)) {
+    case RT_REF_LIST: { // HittableList: entries in order (hittable_list.rs:45-51)
+        const uint32_t e = sc.list_entries[idx];
+        if (e != RT_REF_NONE) {
+            st.push(RT_MAKE_REF(RT_REF_LIST, idx + 1u));
+            s.cur = e;
+            return;
+        }
+        break;
+    }
+    case RT_REF_INST: {
+        const RtInst in = sc.insts[idx];
+        st.push(RT_MAKE_REF(RT_REF_POP, idx));
+        s.r = rt_apply_inst(in, s.r);
+        s.inv = rt_inv_dir(s.r);
+        s.cur = in.child;
+        return;
+    }
+    case RT_REF_POP: { // leave instance idx: back to the ray of its own frame
+        s.r = rt_ray_to_level(sc, world_ray(), sc.insts[idx].parent_inst);
+        s.inv = rt_inv_dir(s.r);
+        break;
+    }
+    default: rt_test_leaf(sc, s.cur, s.r, t_min, s.best, xi, skip_media); break;
+    }
+    s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop();
+}
+
+// Everything below `root`, per lane, starting from an empty stack. `r` is the ray of root's frame.
+template <class Stack, class XiFn, class RayFn>
+RT_HD void rt_traverse(const DScene& sc, uint32_t root, const Ray& r, double t_min, RtBest& best, Stack& st, const XiFn& xi,
                        bool skip_media, const RayFn& world_ray) {
-    V3 inv = rt_inv_dir(r);
-    uint32_t cur = root;
+    RtTrav s;
+    s.r = r;
+    s.inv = rt_inv_dir(r);
+    s.best = best;
+    s.cur = root;
 #pragma unroll 1
     for (;;) {
-        // descend: box tests only
+        rt_trav_descend(sc, s, st, t_min);
+        if (s.cur == RT_REF_NONE) break;
+        rt_trav_visit(sc, s, st, t_min, xi, skip_media, world_ray);
+    }
+    best = s.best;
+}
+
+// The world entries that are a primitive or a medium, possibly wrapped in Translate / RotateY: every lane
+// tests the same entry at the same time, so entry and parameters are wave-uniform (scalar loads, no stack).
+template <class XiFn, class RayFn>
+RT_HD void rt_extend_flat(const DScene& sc, const RayFn& world_ray, double t_min, RtBest& best, const XiFn& xi, bool skip_media) {
+    Ray r = world_ray();
 #pragma unroll 1
-        while (RT_REF_TYPE(cur) == RT_REF_NODE) {
-            const RtNode n = sc.nodes[RT_REF_INDEX(cur)];
-            if (rt_aabb_hit(n, r, inv, t_min, best.t)) {
-                if (n.right != RT_REF_NONE) st.push(n.right);
-                cur = n.left;
-            } else {
-                cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop();
-            }
-        }
-        if (cur == RT_REF_NONE) break;
-        const uint32_t idx = RT_REF_INDEX(cur);
-        switch (RT_REF_TYPE(cur)) {
-        case RT_REF_LIST: { // a HittableList below a BVH or instance: entries in order
-            const uint32_t e = sc.list_entries[idx];
-            if (e != RT_REF_NONE) {
-                st.push(RT_MAKE_REF(RT_REF_LIST, idx + 1u));
-                cur = e;
-                continue;
-            }
-            break;
-        }
-        case RT_REF_INST: {
-            const RtInst in = sc.insts[idx];
-            st.push(RT_MAKE_REF(RT_REF_POP, idx));
+    for (uint32_t li = RT_REF_INDEX(sc.world_flat);; ++li) {
+        uint32_t e = sc.list_entries[li];
+        if (e == RT_REF_NONE) break;
+        bool moved = false;
+#pragma unroll 1
+        while (RT_REF_TYPE(e) == RT_REF_INST) {
+            const RtInst in = sc.insts[RT_REF_INDEX(e)];
             r = rt_apply_inst(in, r);
-            inv = rt_inv_dir(r);
-            cur = in.child;
-            continue;
+            e = in.child;
+            moved = true;
         }
-        case RT_REF_POP: { // leave instance idx: back to the ray of its own frame
-            r = rt_ray_to_level(sc, world_ray(), sc.insts[idx].parent_inst);
-            inv = rt_inv_dir(r);
-            break;
-        }
-        default: rt_test_leaf(sc, cur, r, t_min, best, xi, skip_media); break;
-        }
-        cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop();
+        rt_test_leaf(sc, e, r, t_min, best, xi, skip_media);
+        if (moved) r = world_ray();
     }
 }
 
@@ -354,25 +404,9 @@ RT_HD RtHitLite rt_extend(const DScene& sc, const RayFn& world_ray, double t_min
     best.t = t_max;
     best.ref = RT_REF_NONE;
     best.aux = 0u;
-    Ray r = world_ray();
-#pragma unroll 1
-    for (uint32_t li = RT_REF_INDEX(sc.world);; ++li) {
-        uint32_t e = sc.list_entries[li];
-        if (e == RT_REF_NONE) break;
-        // Translate / RotateY wrapped around the whole entry: the same for every lane
-        bool moved = false;
-#pragma unroll 1
-        while (RT_REF_TYPE(e) == RT_REF_INST) {
-            const RtInst in = sc.insts[RT_REF_INDEX(e)];
-            r = rt_apply_inst(in, r);
-            e = in.child;
-            moved = true;
-        }
-        const uint32_t ty = RT_REF_TYPE(e);
-        if (ty == RT_REF_NODE || ty == RT_REF_LIST) rt_traverse(sc, e, r, t_min, best, st, xi, skip_media, world_ray);
-        else rt_test_leaf(sc, e, r, t_min, best, xi, skip_media);
-        if (moved) r = world_ray();
-    }
+    rt_extend_flat(sc, world_ray, t_min, best, xi, skip_media);
+    if (sc.list_entries[RT_REF_INDEX(sc.world_tree)] != RT_REF_NONE)
+        rt_traverse(sc, sc.world_tree, world_ray(), t_min, best, st, xi, skip_media, world_ray);
     RtHitLite h;
     h.t = best.t;
     h.ref = best.ref;

@@ -29,6 +29,8 @@
 #include "rt_device.h"
 
 #define RT_BLOCK 256
+#define RT_TREE_CHUNK 1024u /* queue indices a persistent wave reserves per atomic */
+#define RT_BIN_PER_THREAD 8  /* rays per thread in k_bin */
 #define RT_COUNTER_STRIDE 8u /* per iteration: [0] live paths entering it, [1+m] hits on material type m */
 
 // ---- device structures ------------------------------------------------------------------------------------
@@ -63,9 +65,11 @@ struct LdsStack {
     __device__ bool empty() const { return sp == 0u; }
 };
 
-struct PhiloxXi { // the uniform a ConstantMedium draws (constant_medium.rs:53)
-    Sampler s;
-    __device__ double operator()(uint32_t medium_index) const { return sampler_draw1(s, RT_STREAM_MEDIUM0 + medium_index, 0u); }
+struct PassInfo;
+struct PhiloxXi { // the uniform a ConstantMedium draws (constant_medium.rs:53) for path `slot` at bounce `bounce`
+    const PassInfo* pi;
+    uint32_t slot, bounce;
+    __device__ double operator()(uint32_t medium_index) const;
 };
 struct ArrayXi { // injected uniforms for rt_trace_first_hit
     const double* row;
@@ -82,6 +86,37 @@ __device__ inline void wave_append(bool take, uint32_t slot, uint32_t* q, uint32
     if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
     base = __shfl(base, (int)leader);
     if (take) q[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
+}
+
+// The same for a whole workgroup and R items per thread: ONE atomic per call (a single counter word takes only
+// ~90 atomics per microsecond chip-wide, so per-wave appends of millions of waves would serialise on it).
+// `scratch` = RT_BLOCK/64 + 1 words of LDS. Every thread of the block must call it.
+template <int R>
+__device__ inline void block_append(const bool (&take)[R], const uint32_t (&slot)[R], uint32_t* q, uint32_t* counter,
+                                    uint32_t* scratch) {
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    uint32_t rank[R];
+    uint32_t mine = 0u;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned long long mask = __ballot(take[r]);
+        rank[r] = mine + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        mine += (uint32_t)__popcll(mask);
+    }
+    // `mine` is now the wave's total (identical in every lane)
+    __syncthreads();
+    if (lane == 0u) scratch[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t total = 0u;
+        for (uint32_t w = 0; w < RT_BLOCK / 64u; ++w) { const uint32_t c = scratch[w]; scratch[w] = total; total += c; }
+        scratch[RT_BLOCK / 64u] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    const uint32_t base = scratch[RT_BLOCK / 64u] + scratch[wave];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (take[r]) q[base + rank[r]] = slot[r];
 }
 
 __device__ inline Ray load_ray(const PathBufs& pb, uint32_t slot) {
@@ -109,6 +144,10 @@ __device__ inline Sampler slot_sampler(const PassInfo& pi, uint32_t slot, uint32
     return sampler_make(pi.pixmap[lp], pi.sample_offset + s, bounce, pi.seed);
 }
 
+__device__ double PhiloxXi::operator()(uint32_t medium_index) const {
+    return sampler_draw1(slot_sampler(*pi, slot, bounce), RT_STREAM_MEDIUM0 + medium_index, 0u);
+}
+
 // ---- kernels ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtCameraDev cam, PassInfo pi, PathBufs pb) {
     const uint32_t n = pi.n_local * pi.S;
@@ -126,56 +165,171 @@ __global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtCameraDev cam, PassInfo p
     }
 }
 
-// world.hit(r, 0.001, INFINITY, rec) (main.rs:56) for every live path of iteration `it`.
-__global__ void __launch_bounds__(RT_BLOCK) k_extend(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
-                                                     uint32_t stack_cap) {
+// world.hit(r, 0.001, INFINITY, rec) (main.rs:56) for every live path of iteration `it`, in three launches:
+//
+//   k_extend_flat   the world entries that are plain primitives or media, every lane in lock step
+//   k_extend_tree   the world entries that are BVHs, per lane with a stack, persistent waves (below)
+//   k_bin           misses take the background and end; hits are queued by material type
+//
+// The closest hit is the minimum over all entries whatever the order they are tested in, so the flat pass
+// seeds pb.hit[slot] and the tree pass only improves on it.
+
+__global__ void __launch_bounds__(RT_BLOCK) k_extend_flat(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it) {
+    const uint32_t* live = it == 0u ? nullptr : qs.live[it & 1u];
+    const uint32_t n = qs.counters[it * RT_COUNTER_STRIDE];
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+        const uint32_t slot = live ? live[i] : i;
+        SlotRay ray_of;
+        ray_of.pb = &pb; ray_of.slot = slot;
+        PhiloxXi xi;
+        xi.pi = &pi; xi.slot = slot; xi.bounce = it;
+        RtBest best;
+        best.t = RT_INF; best.ref = RT_REF_NONE; best.aux = 0u;
+        rt_extend_flat(sc, ray_of, 0.001, best, xi, false);
+        RtHitLite h;
+        h.t = best.t; h.ref = best.ref; h.aux = best.aux;
+        pb.hit[slot] = h;
+    }
+}
+
+// Persistent waves. Once rays are incoherent the number of box tests differs by an order of magnitude from
+// lane to lane, and box tests and leaf tests interleave differently in every lane. So:
+//  * a lane that has finished its ray does not wait for the slowest one: when `refill_min` lanes of a wave
+//    are out of work they take the next rays of the queue (one atomic on the queue head per refill);
+//  * box tests run for all lanes that hold a node until `leaf_min` lanes wait at a leaf; then those
+//    leaves are tested together.
+// Which lane traces which ray, and when, has no effect on results.
+__global__ void __launch_bounds__(RT_BLOCK) k_extend_tree(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
+                                                          uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_min,
+                                                          uint32_t seeded) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t* live = it == 0u ? nullptr : qs.live[it & 1u];
     uint32_t* ctr = qs.counters + it * RT_COUNTER_STRIDE;
     const uint32_t n = ctr[0];
+    uint32_t* head = ctr + 6u;
     LdsStack st;
     st.base = lds_stack + threadIdx.x;
     st.cap = stack_cap;
     st.error_flag = qs.error_flag;
-    // whole waves iterate together so that the ballots below see every lane
-    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
-        const uint32_t i = base + threadIdx.x;
-        const bool active = i < n;
-        uint32_t slot = 0u;
-        uint32_t mat_type = 0xFFFFFFFFu;
-        if (active) {
-            slot = live ? live[i] : i;
+    st.sp = 0u;
+    const uint32_t lane = __lane_id();
+    RtTrav s;
+    s.cur = RT_REF_NONE;
+    s.best.t = RT_INF; s.best.ref = RT_REF_NONE; s.best.aux = 0u;
+    uint32_t slot = 0u;
+    bool active = false;    // tracing a ray
+    bool exhausted = false; // wave-uniform: the queue has no more rays
+    // the wave draws queue indices from a private chunk and takes a new chunk (one atomic) when it runs out
+    // (chunk size: large enough to keep atomics rare, small enough that every wave of the grid gets several)
+    uint32_t chunk_next = 0u, chunk_end = 0u;
+    const uint32_t chunk = max(64u, min((uint32_t)RT_TREE_CHUNK, (n / (gridDim.x * (RT_BLOCK / 64u) * 8u)) & ~63u));
+#pragma unroll 1
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle == 64u && exhausted) break;
+        if (n_idle >= refill_min && !exhausted) { // hand idle lanes the next rays
+            if (chunk_next >= chunk_end) {
+                uint32_t c = 0u;
+                if (lane == 0u) c = atomicAdd(head, chunk);
+                chunk_next = __shfl(c, 0);
+                chunk_end = chunk_next + chunk;
+            }
+            const uint32_t base = chunk_next;
+            chunk_next = min(chunk_next + n_idle, chunk_end); // lanes past the end of the chunk stay idle until the next refill
+            if (!active) {
+                const uint32_t i = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (i < n && i < chunk_end) {
+                    slot = live ? live[i] : i;
+                    s.r = load_ray(pb, slot);
+                    s.inv = rt_inv_dir(s.r);
+                    if (seeded) {
+                        const RtHitLite h = pb.hit[slot];
+                        s.best.t = h.t; s.best.ref = h.ref; s.best.aux = h.aux;
+                    } else {
+                        s.best.t = RT_INF; s.best.ref = RT_REF_NONE; s.best.aux = 0u;
+                    }
+                    s.cur = sc.world_tree;
+                    st.sp = 0u;
+                    active = true;
+                }
+            }
+            if (chunk_next >= n) exhausted = true;
+            if (__ballot(active) == 0ull && exhausted) break;
+        }
+        // ---- box tests: every lane that holds a node steps ----
+#pragma unroll 1
+        for (;;) {
+            const bool at_node = active && RT_REF_TYPE(s.cur) == RT_REF_NODE;
+            if (__ballot(at_node) == 0ull) break;
+            if ((uint32_t)__popcll(__ballot(active && !at_node)) >= leaf_min) break;
+            if (at_node) rt_trav_node_step(sc, s, st, 0.001);
+        }
+        // ---- one non-node reference for every lane that holds one ----
+        if (active && s.cur != RT_REF_NONE && RT_REF_TYPE(s.cur) != RT_REF_NODE) {
             SlotRay ray_of;
             ray_of.pb = &pb; ray_of.slot = slot;
             PhiloxXi xi;
-            xi.s = slot_sampler(pi, slot, it);
-            st.sp = 0u;
-            const RtHitLite h = rt_extend(sc, ray_of, 0.001, RT_INF, st, xi, false);
+            xi.pi = &pi; xi.slot = slot; xi.bounce = it;
+            rt_trav_visit(sc, s, st, 0.001, xi, false, ray_of);
+        }
+        if (active && s.cur == RT_REF_NONE) { // finished: publish the closest hit
+            RtHitLite h;
+            h.t = s.best.t; h.ref = s.best.ref; h.aux = s.best.aux;
             pb.hit[slot] = h;
-            if (h.ref == RT_REF_NONE) { // main.rs:56-58: return background
-                const V3 bg = rt_background(pi.bg, pi.bg_mode, ray_of());
-                pb.rr[slot] += pb.tr[slot] * bg.x;
-                pb.rg[slot] += pb.tg[slot] * bg.y;
-                pb.rb[slot] += pb.tb[slot] * bg.z;
-            } else {
-                uint32_t m;
-                const uint32_t ty = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
-                if (ty == RT_REF_SPHERE) m = sc.sphere_meta[idx].material;
-                else if (ty == RT_REF_MSPHERE) m = sc.msphere_meta[idx].material;
-                else if (ty == RT_REF_RECT) m = sc.rect_meta[idx].material;
-                else if (ty == RT_REF_BOX) m = sc.box_meta[idx].material;
-                else m = sc.media[idx].material;
-                mat_type = sc.materials[m].type;
+            active = false;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_bin(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it) {
+    __shared__ uint32_t scratch[RT_BLOCK / 64 + 1];
+    const uint32_t* live = it == 0u ? nullptr : qs.live[it & 1u];
+    uint32_t* ctr = qs.counters + it * RT_COUNTER_STRIDE;
+    const uint32_t n = ctr[0];
+    const uint32_t per_block = RT_BLOCK * RT_BIN_PER_THREAD;
+    // whole blocks iterate together: block_append synchronises the block
+    for (uint32_t base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
+        uint32_t slot[RT_BIN_PER_THREAD], mat_type[RT_BIN_PER_THREAD];
+#pragma unroll
+        for (int r = 0; r < RT_BIN_PER_THREAD; ++r) {
+            const uint32_t i = base + (uint32_t)r * RT_BLOCK + threadIdx.x;
+            slot[r] = 0u;
+            mat_type[r] = 0xFFFFFFFFu;
+            if (i < n) {
+                slot[r] = live ? live[i] : i;
+                const RtHitLite h = pb.hit[slot[r]];
+                if (h.ref == RT_REF_NONE) { // main.rs:56-58: return background
+                    const V3 bg = rt_background(pi.bg, pi.bg_mode, load_ray(pb, slot[r]));
+                    pb.rr[slot[r]] += pb.tr[slot[r]] * bg.x;
+                    pb.rg[slot[r]] += pb.tg[slot[r]] * bg.y;
+                    pb.rb[slot[r]] += pb.tb[slot[r]] * bg.z;
+                } else {
+                    uint32_t m;
+                    const uint32_t ty = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
+                    if (ty == RT_REF_SPHERE) m = sc.sphere_meta[idx].material;
+                    else if (ty == RT_REF_MSPHERE) m = sc.msphere_meta[idx].material;
+                    else if (ty == RT_REF_RECT) m = sc.rect_meta[idx].material;
+                    else if (ty == RT_REF_BOX) m = sc.box_meta[idx].material;
+                    else m = sc.media[idx].material;
+                    mat_type[r] = sc.materials[m].type;
+                }
             }
         }
+#pragma unroll 1
+        for (uint32_t m = 0; m < RT_MAT_COUNT; ++m) {
+            bool take[RT_BIN_PER_THREAD];
 #pragma unroll
-        for (uint32_t m = 0; m < RT_MAT_COUNT; ++m) wave_append(active && mat_type == m, slot, qs.bucket[m], ctr + 1u + m);
+            for (int r = 0; r < RT_BIN_PER_THREAD; ++r) take[r] = mat_type[r] == m;
+            block_append<RT_BIN_PER_THREAD>(take, slot, qs.bucket[m], ctr + 1u + m, scratch);
+        }
     }
 }
 
 // emitted + scatter (main.rs:60-70) for every path of iteration `it` that hit a material of type MAT.
 template <uint32_t MAT>
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it) {
+    __shared__ uint32_t scratch[RT_BLOCK / 64 + 1];
     const uint32_t* bucket = qs.bucket[MAT];
     const uint32_t n = qs.counters[it * RT_COUNTER_STRIDE + 1u + MAT];
     uint32_t* next = qs.live[(it + 1u) & 1u];
@@ -213,7 +367,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
                 pb.tr[slot] *= o.attenuation.x; pb.tg[slot] *= o.attenuation.y; pb.tb[slot] *= o.attenuation.z;
             }
         }
-        wave_append(alive, slot, next, next_counter);
+        const bool take[1] = {alive};
+        const uint32_t slots[1] = {slot};
+        block_append<1>(take, slots, next, next_counter, scratch);
     }
 }
 
@@ -290,6 +446,7 @@ struct rt_scene {
     size_t nbytes = 0;
     RtBlobHeader hdr;
     DScene view;
+    bool has_flat = true, has_tree = true; // whether the world holds plain primitives / BVHs at all
 };
 
 struct rt_context {
@@ -310,6 +467,8 @@ struct rt_context {
     uint32_t pm_w = 0, pm_h = 0, pm_tile = 0, pm_rank = 0, pm_world = 0, pm_n = 0;
     size_t pm_cap = 0;
     std::vector<hipEvent_t> events;
+    // k_extend thresholds (lanes of a wave): refill once this many lanes are out of work, test leaves once this many wait
+    uint32_t tune_refill = 16, tune_leaf = 32;
 };
 
 namespace {
@@ -365,6 +524,8 @@ void make_view(rt_scene* s) {
     v.perlin_perm = (const int32_t*)(b + h.perlin_perm.offset);
     v.texels = (const uint8_t*)(b + h.texels.offset);
     v.world = h.world;
+    v.world_flat = h.world_flat;
+    v.world_tree = h.world_tree;
     v.n_media = h.n_media;
     v.compat = 0;
 }
@@ -484,6 +645,8 @@ int rt_init(rt_context** out, int device) {
         return RT_ERR_OOM;
     }
     hipMemset(ctx->error_flag, 0, sizeof(uint32_t));
+    if (const char* e = getenv("RT_TUNE_REFILL")) ctx->tune_refill = (uint32_t)std::max(1, std::min(64, atoi(e)));
+    if (const char* e = getenv("RT_TUNE_LEAF")) ctx->tune_leaf = (uint32_t)std::max(1, std::min(64, atoi(e)));
     *out = ctx;
     return RT_OK;
 }
@@ -521,6 +684,17 @@ static int upload_common(rt_context* ctx, const void* src, size_t nbytes, bool s
     if (e != hipSuccess) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_NO_DEVICE, "copy scene", e); }
     s->nbytes = nbytes;
     make_view(s);
+    {   // first entry of the two world sub-lists: NONE = that list is empty and its kernel can be skipped
+        uint32_t first[2] = {RT_REF_NONE, RT_REF_NONE};
+        const uint32_t idx[2] = {RT_REF_INDEX(s->hdr.world_flat), RT_REF_INDEX(s->hdr.world_tree)};
+        for (int k = 0; k < 2; ++k) {
+            if (idx[k] >= s->hdr.list_entries.count) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_INVALID, "blob: world list out of range"); }
+            e = hipMemcpy(&first[k], (const uint8_t*)s->d_blob + s->hdr.list_entries.offset + 4u * idx[k], 4, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_NO_DEVICE, "read world lists", e); }
+        }
+        s->has_flat = first[0] != RT_REF_NONE;
+        s->has_tree = first[1] != RT_REF_NONE;
+    }
     *out = s;
     return RT_OK;
 }
@@ -632,7 +806,11 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
 
     const uint32_t stack_cap = sc->hdr.stack_need;
     const size_t lds = (size_t)stack_cap * RT_BLOCK * sizeof(uint32_t);
-    const uint32_t extend_blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds, 1)));
+    const bool has_flat = sc->has_flat, has_tree = sc->has_tree;
+    // persistent waves: as many blocks as are resident at once (more would only find the queue empty)
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_extend_tree, RT_BLOCK, lds) != hipSuccess || occ < 1) occ = 2;
+    const uint32_t extend_blocks_per_cu = (uint32_t)occ;
     const size_t n_counters = (size_t)(p->max_depth + 2) * RT_COUNTER_STRIDE;
     std::vector<uint32_t> host_counters(n_counters);
 
@@ -659,7 +837,11 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
         const uint32_t g_sh = grid_for(ctx, paths, 8);
         for (uint32_t it = 0; it < p->max_depth; ++it) {
             a = tm.begin();
-            hipLaunchKernelGGL(k_extend, dim3(g_ext), dim3(RT_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it, stack_cap);
+            if (has_flat) hipLaunchKernelGGL(k_extend_flat, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);
+            if (has_tree || !has_flat)
+                hipLaunchKernelGGL(k_extend_tree, dim3(g_ext), dim3(RT_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it, stack_cap,
+                                   ctx->tune_refill, ctx->tune_leaf, has_flat ? 1u : 0u);
+            hipLaunchKernelGGL(k_bin, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);
             tm.end(a, 1);
             launch_shade<RT_MAT_LAMBERTIAN>(ctx, &local, pi, pb, qs, it, g_sh, tm);
             launch_shade<RT_MAT_METAL>(ctx, &local, pi, pb, qs, it, g_sh, tm);

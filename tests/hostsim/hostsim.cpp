@@ -59,6 +59,8 @@ bool view_of(const void* blob, size_t nbytes, DScene& v, RtBlobHeader& h) {
     v.perlin_perm = (const int32_t*)(b + h.perlin_perm.offset);
     v.texels = (const uint8_t*)(b + h.texels.offset);
     v.world = h.world;
+    v.world_flat = h.world_flat;
+    v.world_tree = h.world_tree;
     v.n_media = h.n_media;
     v.compat = 0;
     return true;

@@ -81,15 +81,15 @@ def test_unsupported_shapes_are_refused_at_compile_time():
     assert e.value.code == _lib.RT_ERR_UNSUPPORTED
 
 
-HEADER = struct.Struct("<IIQIIIIII")  # magic, version, total, world, n_media, stack_need, max_chain, flags, n_objects
+HEADER = struct.Struct("<IIQIIIIIIII")  # magic, version, total, world, world_flat, world_tree, n_media, stack_need, max_chain, flags, n_objects
 
 
 def header(blob):
-    magic, version, total, world, n_media, stack_need, max_chain, flags, n_objects = HEADER.unpack_from(blob, 0)
+    magic, version, total, world, world_flat, world_tree, n_media, stack_need, max_chain, flags, n_objects = HEADER.unpack_from(blob, 0)
     secs = np.frombuffer(blob, dtype="<u8", count=17 * 2, offset=HEADER.size).reshape(17, 2)
     names = ["nodes", "spheres", "sphere_meta", "mspheres", "msphere_meta", "rects", "rect_meta", "boxes", "box_meta", "media",
              "insts", "list_entries", "materials", "textures", "perlin_vec", "perlin_perm", "texels"]
-    return dict(magic=magic, version=version, total=total, world=world, n_media=n_media, stack_need=stack_need,
+    return dict(magic=magic, version=version, total=total, world=world, world_flat=world_flat, world_tree=world_tree, n_media=n_media, stack_need=stack_need,
                 max_chain=max_chain, flags=flags, n_objects=n_objects, sections={n: tuple(map(int, s)) for n, s in zip(names, secs)})
 
 
@@ -110,6 +110,12 @@ def test_blob_layout_of_the_book2_final_scene():
     world_first = h["world"] & 0x0FFFFFFF
     entries = np.frombuffer(blob, dtype="<u4", count=s["list_entries"][1], offset=s["list_entries"][0])
     assert (h["world"] >> 28) == 8 and np.count_nonzero(entries[world_first:world_first + 11]) == 11 and entries[world_first + 11] == 0
+    # the same 11 entries again, split into the 9 primitives / media and the 2 trees (BVH of boxes, instanced BVH of spheres)
+    flat_first, tree_first = h["world_flat"] & 0x0FFFFFFF, h["world_tree"] & 0x0FFFFFFF
+    flat, tree = entries[flat_first:flat_first + 10], entries[tree_first:tree_first + 3]
+    assert np.count_nonzero(flat[:9]) == 9 and flat[9] == 0 and np.count_nonzero(tree[:2]) == 2 and tree[2] == 0
+    assert sorted(np.concatenate([flat[:9], tree[:2]]).tolist()) == sorted(entries[world_first:world_first + 11].tolist())
+    assert (tree[0] >> 28) == 1 and (tree[1] >> 28) == 7
 
 
 def test_cornell_has_seven_nodes_and_f32_bounds_contain_the_f64_boxes():

@@ -28,13 +28,15 @@ def test_first_hit_matches_oracle(name):
     rep = util.first_hit_report(got, want)
     assert rep["prim_match"] == 1.0, rep
     assert rep["t_bit_equal"] == 1.0, rep                          # same libm on both sides here: exact
+    assert rep["ties"] < 0.01
+    same = got["prim_id"] == want["prim_id"]
     for f in ("px", "py", "pz", "nx", "ny", "nz"):
-        assert np.array_equal(got[f].view(np.uint64), want[f].view(np.uint64)), f     # bit compare: NaN == NaN
-    assert np.array_equal(got["flags"], want["flags"]) and np.array_equal(got["material_id"], want["material_id"])
+        assert np.array_equal(got[f][same].view(np.uint64), want[f][same].view(np.uint64)), f     # bit compare: NaN == NaN
+    assert np.array_equal(got["flags"][same], want["flags"][same]) and np.array_equal(got["material_id"][same], want["material_id"][same])
     # u, v: equal wherever the reference writes them; MovingSphere and ConstantMedium leave stale values behind
     # (moving_sphere.rs:63-68, constant_medium.rs:59-65) where the product reports 0
     same_uv = (got["u"].view(np.uint64) == want["u"].view(np.uint64)) & (got["v"].view(np.uint64) == want["v"].view(np.uint64))
-    differs = ~same_uv & (want["prim_id"] != MISS)
+    differs = ~same_uv & (want["prim_id"] != MISS) & same
     assert np.all(np.isin(want["prim_id"][differs], util.ids_without_uv(desc)))
     assert np.all((got["u"][differs] == 0.0) & (got["v"][differs] == 0.0))
     assert (want["prim_id"] != MISS).mean() > 0.3
@@ -44,10 +46,7 @@ def test_first_hit_matches_oracle(name):
     # makes what gets clipped depend on the tree (cornell_box).
     if name != "cornell_box":
         other = ck.OracleScene(desc, bvh_seed=77, share_bvh_axes=False).trace_first_hit(rays, xi)
-        # (an axis-parallel ray lying in a rect's plane gives t = 0/0 = NaN at arrect.rs:32, which passes every range
-        # test; once closest_so_far is NaN everything tested later is accepted, so those rays are order-dependent too)
-        generic = (rays["dx"] != 0) & (rays["dy"] != 0) & (rays["dz"] != 0)
-        differs = (other["prim_id"] != got["prim_id"]) & generic
+        differs = other["prim_id"] != got["prim_id"]
         assert np.array_equal(other["t"][differs].view(np.uint64), got["t"][differs].view(np.uint64))
         assert differs.mean() < 0.03
 

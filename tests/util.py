@@ -43,9 +43,12 @@ def ray_suite(camera_rays, hits, rng, n_secondary=None):
         d = rng.normal(size=p.shape)
         sec = rays_from(p, d, time=rng.random(len(p)))
         out.append(sec)
+        # exact zeros in the direction (1/0 = inf in the slab test, aabb.rs:36), started just off the surface: a ray lying
+        # exactly in a rect's plane gives t = 0/0 = NaN (arrect.rs:32), which passes every later range test and makes
+        # the reference's own answer depend on its test order
         axis = np.zeros_like(p)
         axis[np.arange(len(p)), rng.integers(0, 3, len(p))] = rng.choice([-1.0, 1.0], len(p))
-        out.append(rays_from(p, axis, time=rng.random(len(p))))
+        out.append(rays_from(p + rng.uniform(-1e-3, 1e-3, p.shape), axis, time=rng.random(len(p))))
         short = rays_from(p, d, time=rng.random(len(p)), tmin=-5.0, tmax=rng.random(len(p)) * 300.0)
         out.append(short)
     return np.concatenate(out)
@@ -70,12 +73,20 @@ def abs_err(got, want):
 
 
 def first_hit_report(got, want):
-    """Parity numbers for two rt_hit arrays of the same rays."""
+    """Parity numbers for two rt_hit arrays of the same rays.
+
+    An exact tie - two different primitives reached at bit-identical t, e.g. the coincident faces of neighbouring
+    boxes - is not a mismatch: which of them wins depends only on the order they are tested in, and the reference's
+    own order depends on the random split axes of its BVH (bvh.rs:22). The kernels test the world's plain primitives
+    before its BVHs, so their tie winners can differ from the oracle's. Ties are reported separately."""
     same_prim = got["prim_id"] == want["prim_id"]
+    tie = ~same_prim & (got["prim_id"] != 0xFFFFFFFF) & (want["prim_id"] != 0xFFFFFFFF) & \
+        (got["t"].view(np.uint64) == want["t"].view(np.uint64))
     both_hit = same_prim & (want["prim_id"] != 0xFFFFFFFF)
     t_rel = rel_err(got["t"][both_hit], want["t"][both_hit])
     return {
-        "prim_match": float(same_prim.mean()),
+        "prim_match": float((same_prim | tie).mean()),
+        "ties": float(tie.mean()),
         "t_rel_max": float(t_rel.max()) if t_rel.size else 0.0,
         "t_bit_equal": float((got["t"][both_hit].view(np.uint64) == want["t"][both_hit].view(np.uint64)).mean()) if both_hit.any() else 1.0,
         "both_hit": both_hit,
