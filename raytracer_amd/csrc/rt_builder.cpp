@@ -147,6 +147,31 @@ bool rt_builder::bounding_box(int h, double t0, double t1, AABB& out) const {
     return false;
 }
 
+// Bounds, in the frame `h` lives in, of everything a ray can hit below `h`, for the objects that own a tree: a
+// BvhNode's box, carried outward through Translate / RotateY (rotating the box, which the reference's RotateY
+// computes and drops, hittable.rs:117-143). false = unknown (treated as unbounded).
+bool rt_builder::world_bound(int h, AABB& out) const {
+    const ObjRec& o = objs[h];
+    if (o.kind == OBJ_BVH) { out = o.box; return true; }
+    if (o.kind == OBJ_TRANSLATE) {
+        if (!world_bound(o.child, out)) return false;
+        for (int i = 0; i < 3; ++i) { out.lo[i] += o.d[i]; out.hi[i] += o.d[i]; }
+        return true;
+    }
+    if (o.kind == OBJ_ROTATE_Y) {
+        AABB c;
+        if (!world_bound(o.child, c)) return false;
+        for (int i = 0; i < 3; ++i) { out.lo[i] = kInf; out.hi[i] = -kInf; }
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int k = 0; k < 2; ++k) {
+            const double x = i ? c.hi[0] : c.lo[0], y = j ? c.hi[1] : c.lo[1], z = k ? c.hi[2] : c.lo[2];
+            const double t[3] = {o.d[1] * x + o.d[0] * z, y, o.d[1] * z - o.d[0] * x};
+            for (int a = 0; a < 3; ++a) { out.lo[a] = std::min(out.lo[a], t[a]); out.hi[a] = std::max(out.hi[a], t[a]); }
+        }
+        return true;
+    }
+    return false;
+}
+
 // BvhNode::new (bvh.rs:15-66). Returns the index of the node created in `tree`, or -1 after fail().
 int rt_builder::build_bvh_node(std::vector<BNode>& tree, std::vector<int>& objects, const std::vector<double>& keys,
                                size_t start, size_t end, double t0, double t1) {
@@ -363,19 +388,67 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     if (wref == RT_REF_NONE) return error.empty() ? fail(RT_ERR_UNSUPPORTED, "empty scene") : RT_ERR_UNSUPPORTED;
     // The closest hit does not depend on the order in which the world's entries are tested (only exact ties do), so the
     // kernels test the entries that are plain primitives or media first, in lock step, and then walk the rest per lane.
+    // The rest (BvhNodes, possibly under Translate/RotateY, nested lists) is hung under a chain of extra nodes
+    //     T_k = { box: union of the world-space bounds of entries k.., left: entry k, right: T_k+1 }
+    // so that per-lane work is box tests only: an entry whose world-space bound the ray misses costs one box test
+    // instead of an instance entry/exit. The extra boxes are supersets of what the entry's own root box admits (with
+    // a 1e-6 relative margin against the rounding of the frame change), so they never cull a hit the reference finds.
     std::vector<uint32_t> flat_refs, tree_refs;
-    for (uint32_t i = RT_REF_INDEX(wref); f.list_entries[i] != RT_REF_NONE; ++i) {
-        uint32_t e = f.list_entries[i], leaf = e;
-        while (RT_REF_TYPE(leaf) == RT_REF_INST) leaf = f.insts[RT_REF_INDEX(leaf)].child;
-        const uint32_t ty = RT_REF_TYPE(leaf);
-        (ty == RT_REF_NODE || ty == RT_REF_LIST ? tree_refs : flat_refs).push_back(e);
+    std::vector<int> tree_handles;
+    {
+        std::vector<int> members;
+        if (objs[world].kind == OBJ_LIST) members = objs[world].members; else members.push_back(world);
+        uint32_t i = RT_REF_INDEX(wref);
+        for (size_t k = 0; k < members.size(); ++k, ++i) {
+            uint32_t e = f.list_entries[i], leaf = e;
+            while (RT_REF_TYPE(leaf) == RT_REF_INST) leaf = f.insts[RT_REF_INDEX(leaf)].child;
+            const uint32_t ty = RT_REF_TYPE(leaf);
+            if (ty == RT_REF_NODE || ty == RT_REF_LIST) { tree_refs.push_back(e); tree_handles.push_back(members[k]); }
+            else flat_refs.push_back(e);
+        }
     }
-    const uint32_t flat_first = (uint32_t)f.list_entries.size();
-    for (uint32_t r : flat_refs) f.list_entries.push_back(r);
-    f.list_entries.push_back(RT_REF_NONE);
-    const uint32_t tree_first = (uint32_t)f.list_entries.size();
-    for (uint32_t r : tree_refs) f.list_entries.push_back(r);
-    f.list_entries.push_back(RT_REF_NONE);
+    uint32_t flat_ref = RT_REF_NONE, tree_ref = RT_REF_NONE;
+    if (!flat_refs.empty()) {
+        flat_ref = RT_MAKE_REF(RT_REF_LIST, f.list_entries.size());
+        for (uint32_t r : flat_refs) f.list_entries.push_back(r);
+        f.list_entries.push_back(RT_REF_NONE);
+    }
+    if (!tree_refs.empty()) {
+        const float inf = std::numeric_limits<float>::infinity();
+        std::vector<RtNode> bounds(tree_refs.size());
+        for (size_t k = 0; k < tree_refs.size(); ++k) {
+            AABB wb;
+            RtNode& n = bounds[k];
+            if (world_bound(tree_handles[k], wb)) {
+                for (int c = 0; c < 3; ++c) {
+                    const double m = 1e-6 * std::max(std::max(std::fabs(wb.lo[c]), std::fabs(wb.hi[c])), wb.hi[c] - wb.lo[c]) + 1e-9;
+                    n.lo[c] = round_down_f32(wb.lo[c] - m);
+                    n.hi[c] = round_up_f32(wb.hi[c] + m);
+                }
+            } else {
+                for (int c = 0; c < 3; ++c) { n.lo[c] = -inf; n.hi[c] = inf; }
+            }
+        }
+        // built back to front so that T_k can point at T_k+1
+        uint32_t next = RT_REF_NONE;
+        RtNode acc = bounds.back();
+        for (size_t k = tree_refs.size(); k-- > 0;) {
+            for (int c = 0; c < 3; ++c) { acc.lo[c] = std::min(acc.lo[c], bounds[k].lo[c]); acc.hi[c] = std::max(acc.hi[c], bounds[k].hi[c]); }
+            uint32_t entry = tree_refs[k];
+            if (RT_REF_TYPE(entry) != RT_REF_NODE) { // give an instance / list its own box in front
+                RtNode w = bounds[k];
+                w.left = entry; w.right = RT_REF_NONE;
+                f.nodes.push_back(w);
+                entry = RT_MAKE_REF(RT_REF_NODE, f.nodes.size() - 1);
+            }
+            if (next == RT_REF_NONE) { next = entry; continue; }
+            RtNode t = acc;
+            t.left = entry; t.right = next;
+            f.nodes.push_back(t);
+            next = RT_MAKE_REF(RT_REF_NODE, f.nodes.size() - 1);
+        }
+        tree_ref = next;
+    }
     const uint32_t stack_need = std::max(1u, need) + 1u;
     if (stack_need > RT_STACK_CAP)
         return fail(RT_ERR_UNSUPPORTED, "scene needs a traversal stack of %u entries, capacity is %u", stack_need, RT_STACK_CAP);
@@ -435,8 +508,8 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     hd.magic = RT_BLOB_MAGIC; hd.version = RT_BLOB_VERSION;
     hd.total_bytes = blob.size();
     hd.world = wref;
-    hd.world_flat = RT_MAKE_REF(RT_REF_LIST, flat_first);
-    hd.world_tree = RT_MAKE_REF(RT_REF_LIST, tree_first);
+    hd.world_flat = flat_ref;
+    hd.world_tree = tree_ref;
     hd.n_media = (uint32_t)n_media;
     hd.stack_need = stack_need;
     hd.max_chain = f.max_chain;

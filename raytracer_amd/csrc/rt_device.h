@@ -343,13 +343,14 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
         const RtInst in = sc.insts[idx];
         st.push(RT_MAKE_REF(RT_REF_POP, idx));
         s.r = rt_apply_inst(in, s.r);
-        s.inv = rt_inv_dir(s.r);
+        if (in.op != RT_OP_TRANSLATE) s.inv = rt_inv_dir(s.r); // a translation leaves the direction, hence 1/d, as it is
         s.cur = in.child;
         return;
     }
     case RT_REF_POP: { // leave instance idx: back to the ray of its own frame
-        s.r = rt_ray_to_level(sc, world_ray(), sc.insts[idx].parent_inst);
-        s.inv = rt_inv_dir(s.r);
+        const RtInst in = sc.insts[idx];
+        s.r = rt_ray_to_level(sc, world_ray(), in.parent_inst);
+        if (in.op != RT_OP_TRANSLATE) s.inv = rt_inv_dir(s.r);
         break;
     }
     default: rt_test_leaf(sc, s.cur, s.r, t_min, s.best, xi, skip_media); break;
@@ -379,6 +380,7 @@ RT_HD void rt_traverse(const DScene& sc, uint32_t root, const Ray& r, double t_m
 // tests the same entry at the same time, so entry and parameters are wave-uniform (scalar loads, no stack).
 template <class XiFn, class RayFn>
 RT_HD void rt_extend_flat(const DScene& sc, const RayFn& world_ray, double t_min, RtBest& best, const XiFn& xi, bool skip_media) {
+    if (sc.world_flat == RT_REF_NONE) return;
     Ray r = world_ray();
 #pragma unroll 1
     for (uint32_t li = RT_REF_INDEX(sc.world_flat);; ++li) {
@@ -405,7 +407,7 @@ RT_HD RtHitLite rt_extend(const DScene& sc, const RayFn& world_ray, double t_min
     best.ref = RT_REF_NONE;
     best.aux = 0u;
     rt_extend_flat(sc, world_ray, t_min, best, xi, skip_media);
-    if (sc.list_entries[RT_REF_INDEX(sc.world_tree)] != RT_REF_NONE)
+    if (sc.world_tree != RT_REF_NONE)
         rt_traverse(sc, sc.world_tree, world_ray(), t_min, best, st, xi, skip_media, world_ray);
     RtHitLite h;
     h.t = best.t;

@@ -684,17 +684,8 @@ static int upload_common(rt_context* ctx, const void* src, size_t nbytes, bool s
     if (e != hipSuccess) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_NO_DEVICE, "copy scene", e); }
     s->nbytes = nbytes;
     make_view(s);
-    {   // first entry of the two world sub-lists: NONE = that list is empty and its kernel can be skipped
-        uint32_t first[2] = {RT_REF_NONE, RT_REF_NONE};
-        const uint32_t idx[2] = {RT_REF_INDEX(s->hdr.world_flat), RT_REF_INDEX(s->hdr.world_tree)};
-        for (int k = 0; k < 2; ++k) {
-            if (idx[k] >= s->hdr.list_entries.count) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_INVALID, "blob: world list out of range"); }
-            e = hipMemcpy(&first[k], (const uint8_t*)s->d_blob + s->hdr.list_entries.offset + 4u * idx[k], 4, hipMemcpyDeviceToHost);
-            if (e != hipSuccess) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_NO_DEVICE, "read world lists", e); }
-        }
-        s->has_flat = first[0] != RT_REF_NONE;
-        s->has_tree = first[1] != RT_REF_NONE;
-    }
+    s->has_flat = s->hdr.world_flat != RT_REF_NONE;
+    s->has_tree = s->hdr.world_tree != RT_REF_NONE;
     *out = s;
     return RT_OK;
 }

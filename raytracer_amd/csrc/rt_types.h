@@ -10,7 +10,7 @@
 #include <stdint.h>
 
 #define RT_BLOB_MAGIC 0x31425452u /* "RTB1" little endian */
-#define RT_BLOB_VERSION 4u
+#define RT_BLOB_VERSION 5u
 
 // ---- tagged references -------------------------------------------------------------------------
 enum RtRefType : uint32_t {
@@ -105,8 +105,8 @@ struct RtBlobHeader {
     uint32_t magic, version;
     uint64_t total_bytes;
     uint32_t world;          // ref of the world HittableList (main.rs:49 takes &Arc<HittableList>), entries in the reference's order
-    uint32_t world_flat;     // the world entries that are a primitive or medium (possibly under Translate/RotateY): tested by every lane in lock step
-    uint32_t world_tree;     // the remaining world entries (BvhNode, nested lists, instances of those): walked per lane with a stack
+    uint32_t world_flat;     // LIST ref (or NONE): the world entries that are a primitive or medium, possibly under Translate/RotateY; tested by every lane in lock step
+    uint32_t world_tree;     // NODE ref (or NONE): the remaining world entries (BvhNodes, instances of them, nested lists) under a chain of bounding nodes; walked per lane with a stack
     uint32_t n_media;        // number of ConstantMedium objects == free-flight draws per segment
     uint32_t stack_need;     // worst-case traversal stack depth for this scene
     uint32_t max_chain;      // deepest instance nesting

@@ -99,7 +99,8 @@ def test_blob_layout_of_the_book2_final_scene():
     assert h["magic"] == 0x31425452 and h["total"] == len(blob) and len(blob) % 256 == 0
     s = h["sections"]
     # BvhNode counts of the reference's recursion (bvh.rs:33-50): 400 boxes -> 511 nodes, 1000 spheres -> 1023
-    assert s["nodes"][1] == 511 + 1023
+    # + 2 bounding nodes the compiler adds above the two trees (one in front of the instanced BVH, one joining both)
+    assert s["nodes"][1] == 511 + 1023 + 2
     assert s["boxes"][1] == 400 and s["mspheres"][1] == 1 and s["rects"][1] == 1
     assert s["spheres"][1] == 1000 + 5 + 2            # + the two medium boundaries (one is the shared r=70 sphere again)
     assert s["media"][1] == 2 == h["n_media"] and s["insts"][1] == 2 and h["max_chain"] == 2
@@ -110,18 +111,30 @@ def test_blob_layout_of_the_book2_final_scene():
     world_first = h["world"] & 0x0FFFFFFF
     entries = np.frombuffer(blob, dtype="<u4", count=s["list_entries"][1], offset=s["list_entries"][0])
     assert (h["world"] >> 28) == 8 and np.count_nonzero(entries[world_first:world_first + 11]) == 11 and entries[world_first + 11] == 0
-    # the same 11 entries again, split into the 9 primitives / media and the 2 trees (BVH of boxes, instanced BVH of spheres)
-    flat_first, tree_first = h["world_flat"] & 0x0FFFFFFF, h["world_tree"] & 0x0FFFFFFF
-    flat, tree = entries[flat_first:flat_first + 10], entries[tree_first:tree_first + 3]
-    assert np.count_nonzero(flat[:9]) == 9 and flat[9] == 0 and np.count_nonzero(tree[:2]) == 2 and tree[2] == 0
-    assert sorted(np.concatenate([flat[:9], tree[:2]]).tolist()) == sorted(entries[world_first:world_first + 11].tolist())
-    assert (tree[0] >> 28) == 1 and (tree[1] >> 28) == 7
+    # the 9 entries that are primitives / media, as a list of their own
+    flat_first = h["world_flat"] & 0x0FFFFFFF
+    flat = entries[flat_first:flat_first + 10]
+    assert (h["world_flat"] >> 28) == 8 and np.count_nonzero(flat[:9]) == 9 and flat[9] == 0
+    assert set(flat[:9].tolist()) <= set(entries[world_first:world_first + 11].tolist())
+    # the 2 trees under bounding nodes: top = {left: BVH of boxes (node 0), right: {left: the Translate instance}}
+    nodes = np.frombuffer(blob, dtype=np.dtype([("lo", "<f4", 3), ("hi", "<f4", 3), ("left", "<u4"), ("right", "<u4")]),
+                          count=s["nodes"][1], offset=s["nodes"][0])
+    assert (h["world_tree"] >> 28) == 1
+    top = nodes[h["world_tree"] & 0x0FFFFFFF]
+    assert top["left"] == (1 << 28) | 0 and (top["right"] >> 28) == 1
+    wrap = nodes[top["right"] & 0x0FFFFFFF]
+    assert (wrap["left"] >> 28) == 7 and wrap["right"] == 0
+    # the instanced cluster: spheres r=10 with centres in [0,165)^3, rotated 15 degrees about y, moved by (-100,270,395)
+    assert np.all(wrap["lo"] < [-100, 265, 345]) and np.all(wrap["hi"] > [60, 430, 540])
+    assert np.all(wrap["lo"] > [-170, 250, 330]) and np.all(wrap["hi"] < [130, 450, 620])
+    assert np.all(top["lo"] <= np.minimum(wrap["lo"], nodes[0]["lo"])) and np.all(top["hi"] >= np.maximum(wrap["hi"], nodes[0]["hi"]))
 
 
 def test_cornell_has_seven_nodes_and_f32_bounds_contain_the_f64_boxes():
     b, info, blob, _ = util.build_scene("cornell_box")
     h = header(blob)
-    assert h["sections"]["nodes"][1] == 7 and h["sections"]["rects"][1] == 6 and h["sections"]["boxes"][1] == 2
+    assert h["sections"]["nodes"][1] == 7 and h["world_tree"] == (1 << 28) | 0 and h["world_flat"] == 0
+    assert h["sections"]["rects"][1] == 6 and h["sections"]["boxes"][1] == 2
     # a BVH over known spheres: every node's f32 box must contain the exact f64 union of its subtree
     rng = np.random.default_rng(3)
     b = api.Builder()
