@@ -76,33 +76,43 @@ RT_HD Ray rt_ray_to_level(const DScene& sc, const Ray& wray, int32_t inst) {
 RT_HD V3 rt_inv_dir(const Ray& r) { return v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z); } // aabb.rs:36,49,62
 
 // AABB::hit (aabb.rs:35-75) on the node's f32 bounds widened to f64. A NaN slab product leaves the
-// interval unchanged exactly as the reference's `if t0 > t_min` selects do.
+// interval unchanged exactly as the reference's `if t0 > t_min` selects do. The reference returns early
+// after each axis; here all three axes are evaluated and the three `t_max <= t_min` verdicts combined,
+// which gives the same answer (the later axes never feed back) without a branch per axis, so the whole
+// 32-byte node can be fetched with one pair of 16-byte loads.
 RT_HD bool rt_aabb_hit(const RtNode& n, const Ray& r, const V3& inv, double t_min, double t_max) {
-    {
-        double t0 = ((double)n.lo[0] - r.o.x) * inv.x;
-        double t1 = ((double)n.hi[0] - r.o.x) * inv.x;
-        if (inv.x < 0.0) { double s = t0; t0 = t1; t1 = s; }
-        t_min = t0 > t_min ? t0 : t_min;
-        t_max = t1 < t_max ? t1 : t_max;
-        if (t_max <= t_min) return false;
-    }
-    {
-        double t0 = ((double)n.lo[1] - r.o.y) * inv.y;
-        double t1 = ((double)n.hi[1] - r.o.y) * inv.y;
-        if (inv.y < 0.0) { double s = t0; t0 = t1; t1 = s; }
-        t_min = t0 > t_min ? t0 : t_min;
-        t_max = t1 < t_max ? t1 : t_max;
-        if (t_max <= t_min) return false;
-    }
-    {
-        double t0 = ((double)n.lo[2] - r.o.z) * inv.z;
-        double t1 = ((double)n.hi[2] - r.o.z) * inv.z;
-        if (inv.z < 0.0) { double s = t0; t0 = t1; t1 = s; }
-        t_min = t0 > t_min ? t0 : t_min;
-        t_max = t1 < t_max ? t1 : t_max;
-        if (t_max <= t_min) return false;
-    }
-    return true;
+    double t0 = ((double)n.lo[0] - r.o.x) * inv.x;
+    double t1 = ((double)n.hi[0] - r.o.x) * inv.x;
+    if (inv.x < 0.0) { double s = t0; t0 = t1; t1 = s; }
+    t_min = t0 > t_min ? t0 : t_min;
+    t_max = t1 < t_max ? t1 : t_max;
+    const bool out_x = t_max <= t_min;
+    t0 = ((double)n.lo[1] - r.o.y) * inv.y;
+    t1 = ((double)n.hi[1] - r.o.y) * inv.y;
+    if (inv.y < 0.0) { double s = t0; t0 = t1; t1 = s; }
+    t_min = t0 > t_min ? t0 : t_min;
+    t_max = t1 < t_max ? t1 : t_max;
+    const bool out_y = t_max <= t_min;
+    t0 = ((double)n.lo[2] - r.o.z) * inv.z;
+    t1 = ((double)n.hi[2] - r.o.z) * inv.z;
+    if (inv.z < 0.0) { double s = t0; t0 = t1; t1 = s; }
+    t_min = t0 > t_min ? t0 : t_min;
+    t_max = t1 < t_max ? t1 : t_max;
+    const bool out_z = t_max <= t_min;
+    return !(out_x | out_y | out_z);
+}
+// One node record as two 16-byte loads (records are 32-byte aligned).
+RT_HD RtNode rt_load_node(const RtNode* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 a = *(const uint4*)p, b = *((const uint4*)p + 1);
+    RtNode n;
+    n.lo[0] = __uint_as_float(a.x); n.lo[1] = __uint_as_float(a.y); n.lo[2] = __uint_as_float(a.z);
+    n.hi[0] = __uint_as_float(a.w); n.hi[1] = __uint_as_float(b.x); n.hi[2] = __uint_as_float(b.y);
+    n.left = b.z; n.right = b.w;
+    return n;
+#else
+    return *p;
+#endif
 }
 
 // Sphere::hit (sphere.rs:34-64): strict delta > 0 and strict t range.
@@ -311,7 +321,7 @@ struct RtTrav {
 // then the left child, the right one kept for later.
 template <class Stack>
 RT_HD void rt_trav_node_step(const DScene& sc, RtTrav& s, Stack& st, double t_min) {
-    const RtNode n = sc.nodes[RT_REF_INDEX(s.cur)];
+    const RtNode n = rt_load_node(sc.nodes + RT_REF_INDEX(s.cur));
     if (rt_aabb_hit(n, s.r, s.inv, t_min, s.best.t)) {
         if (n.right != RT_REF_NONE) st.push(n.right);
         s.cur = n.left;
