@@ -26,12 +26,12 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X vector FP64 spec peak
-# Algorithmic HBM bytes k_extend moves per ray segment in this layout: ray 7 x f64 read (56) + hit record write
-# (16) + live-queue index read (4) + material-queue index write (4).
-EXTEND_BYTES_PER_SEGMENT = 80
-# Whole-path compulsory queue traffic per segment (extend + shade), f64 layout: extend 80 + shade reads ray 56,
-# hit 16, index 4, throughput 24 and writes ray 48, throughput 24, next index 4.
-PATH_BYTES_PER_SEGMENT = 256
+# Algorithmic HBM bytes k_extend_tree moves per ray segment in this layout: live-queue index read (4) + ray 7 x f64
+# read (56) + seed hit record read (16) + hit record write (16).
+EXTEND_BYTES_PER_SEGMENT = 92
+# Whole-path compulsory path-state traffic per segment, f64 layout: flat pass 4 + 56 + 16; tree pass 92; bin
+# 4 + 16 + 4; shade reads 4 + 56 + 16 + 24 (throughput) and writes 48 (next ray) + 24 + 4.
+PATH_BYTES_PER_SEGMENT = 368
 
 
 def cpu_baseline(desc, info, seed, target_seconds):
@@ -56,9 +56,9 @@ def cpu_baseline(desc, info, seed, target_seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--spp", type=int, default=16, help="samples per pixel per GPU per step")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per GPU per step")
     ap.add_argument("--scene", default="final_scene")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     args = ap.parse_args()
@@ -158,7 +158,7 @@ def main():
             "image_sha256": hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest(),
             "image_mean": float(img.mean() / (step_index * spp_step)),
             "roofline": {
-                "kernel": "k_extend", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "kernel": "k_extend_tree", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_segment": EXTEND_BYTES_PER_SEGMENT, "segments_per_launch": seg_per_launch,
                 "avg_launch_ms": avg_ms, "launches": int(stats.extend_launches),
@@ -166,7 +166,8 @@ def main():
                         "not by HBM; the HBM figure is the compulsory path-state traffic only",
             },
             "path_hbm_frac": PATH_BYTES_PER_SEGMENT * (segments / world) / elapsed / 1e9 / HBM_PEAK_GBS,
-            "kernel_ms": {"raygen": stats.raygen_ms, "extend": stats.extend_ms, "accumulate": stats.accumulate_ms,
+            "kernel_ms": {"raygen": stats.raygen_ms, "extend_flat": stats.flat_ms, "extend_tree": stats.extend_ms, "bin": stats.bin_ms,
+                          "accumulate": stats.accumulate_ms,
                           "shade_lambertian": stats.shade_ms[0], "shade_metal": stats.shade_ms[1],
                           "shade_dielectric": stats.shade_ms[2], "shade_diffuse_light": stats.shade_ms[3],
                           "shade_isotropic": stats.shade_ms[4]},

@@ -827,13 +827,20 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
         const uint32_t g_ext = grid_for(ctx, paths, extend_blocks_per_cu);
         const uint32_t g_sh = grid_for(ctx, paths, 8);
         for (uint32_t it = 0; it < p->max_depth; ++it) {
-            a = tm.begin();
-            if (has_flat) hipLaunchKernelGGL(k_extend_flat, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);
-            if (has_tree || !has_flat)
+            if (has_flat) {
+                a = tm.begin();
+                hipLaunchKernelGGL(k_extend_flat, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);
+                tm.end(a, 8);
+            }
+            if (has_tree || !has_flat) {
+                a = tm.begin();
                 hipLaunchKernelGGL(k_extend_tree, dim3(g_ext), dim3(RT_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it, stack_cap,
                                    ctx->tune_refill, ctx->tune_leaf, has_flat ? 1u : 0u);
+                tm.end(a, 1);
+            }
+            a = tm.begin();
             hipLaunchKernelGGL(k_bin, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);
-            tm.end(a, 1);
+            tm.end(a, 9);
             launch_shade<RT_MAT_LAMBERTIAN>(ctx, &local, pi, pb, qs, it, g_sh, tm);
             launch_shade<RT_MAT_METAL>(ctx, &local, pi, pb, qs, it, g_sh, tm);
             launch_shade<RT_MAT_DIELECTRIC>(ctx, &local, pi, pb, qs, it, g_sh, tm);
@@ -860,6 +867,8 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
                 if (sp.kind == 0) { stats->raygen_ms += ms; stats->raygen_launches++; }
                 else if (sp.kind == 1) { stats->extend_ms += ms; stats->extend_launches++; }
                 else if (sp.kind == 7) { stats->accumulate_ms += ms; stats->accumulate_launches++; }
+                else if (sp.kind == 8) { stats->flat_ms += ms; stats->flat_launches++; }
+                else if (sp.kind == 9) { stats->bin_ms += ms; stats->bin_launches++; }
                 else { stats->shade_ms[sp.kind - 2] += ms; stats->shade_launches++; }
             }
             if (p->profile) stats->extend_segments += seg;

@@ -27,5 +27,5 @@ p = api.params_from_info(info, spp_per_pass=a.spp, profile=1, **kw)
 st = api.rt_stats()
 img = ctx.render(sc, info.camera, p, a.spp * a.passes, stats=st)
 print("%s: %d samples, %d segments, %.3f s, %.1f Mrays/s; extend %.2f ms, shade %s ms" %
-      (a.scene, st.camera_samples, st.ray_segments, st.seconds_render, st.ray_segments / st.seconds_render / 1e6, st.extend_ms,
+      (a.scene, st.camera_samples, st.ray_segments, st.seconds_render, st.ray_segments / st.seconds_render / 1e6, st.extend_ms + st.flat_ms + st.bin_ms,
        [round(x, 2) for x in st.shade_ms]))
