@@ -155,20 +155,30 @@ RT_HD bool rt_msphere_t(const RtMSphere& s, const Ray& r, double t_min, double t
     return true;
 }
 
-// One axis-aligned rectangle (arrect.rs:31-40, 83-92, 135-144). axis as in RtRect.
-RT_HD bool rt_rect_t(uint32_t axis, double a0, double a1, double b0, double b1, double k, const Ray& r,
-                     double t_min, double t_max, double& t_out) {
-    double ok, dk, oa, da, ob, db;
-    if (axis == 0u) { ok = r.o.z; dk = r.d.z; oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; }
-    else if (axis == 1u) { ok = r.o.y; dk = r.d.y; oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; }
-    else { ok = r.o.x; dk = r.d.x; oa = r.o.y; da = r.d.y; ob = r.o.z; db = r.d.z; }
-    double t = (k - ok) / dk;
+// One axis-aligned rectangle (arrect.rs:31-40, 83-92, 135-144). AXIS as in RtRect, a compile-time constant so that
+// picking the ray components never turns into indexed access to a copy of the ray in scratch memory.
+template <int AXIS>
+RT_HD bool rt_rect_axis_t(double a0, double a1, double b0, double b1, double k, const Ray& r, double t_min, double t_max,
+                          double& t_out) {
+    const double ok = AXIS == 0 ? r.o.z : (AXIS == 1 ? r.o.y : r.o.x);
+    const double dk = AXIS == 0 ? r.d.z : (AXIS == 1 ? r.d.y : r.d.x);
+    const double oa = AXIS == 2 ? r.o.y : r.o.x;
+    const double da = AXIS == 2 ? r.d.y : r.d.x;
+    const double ob = AXIS == 0 ? r.o.y : r.o.z;
+    const double db = AXIS == 0 ? r.d.y : r.d.z;
+    const double t = (k - ok) / dk;
     if (t < t_min || t > t_max) return false;
-    double a = oa + t * da;
-    double b = ob + t * db;
+    const double a = oa + t * da;
+    const double b = ob + t * db;
     if (a < a0 || a > a1 || b < b0 || b > b1) return false;
     t_out = t;
     return true;
+}
+RT_HD bool rt_rect_t(uint32_t axis, double a0, double a1, double b0, double b1, double k, const Ray& r, double t_min,
+                     double t_max, double& t_out) {
+    if (axis == 0u) return rt_rect_axis_t<0>(a0, a1, b0, b1, k, r, t_min, t_max, t_out);
+    if (axis == 1u) return rt_rect_axis_t<1>(a0, a1, b0, b1, k, r, t_min, t_max, t_out);
+    return rt_rect_axis_t<2>(a0, a1, b0, b1, k, r, t_min, t_max, t_out);
 }
 
 // _Box::hit = HittableList::hit over its six sides in construction order (_box.rs:22-71,
@@ -177,12 +187,12 @@ RT_HD bool rt_rect_t(uint32_t axis, double a0, double a1, double b0, double b1, 
 RT_HD bool rt_box_t(const RtBox& b, const Ray& r, double t_min, double t_max, double& t_out, uint32_t& face) {
     bool hit = false;
     double closest = t_max, t;
-    if (rt_rect_t(0u, b.p0[0], b.p1[0], b.p0[1], b.p1[1], b.p1[2], r, t_min, closest, t)) { hit = true; closest = t; face = 0u; }
-    if (rt_rect_t(0u, b.p0[0], b.p1[0], b.p0[1], b.p1[1], b.p0[2], r, t_min, closest, t)) { hit = true; closest = t; face = 1u; }
-    if (rt_rect_t(1u, b.p0[0], b.p1[0], b.p0[2], b.p1[2], b.p1[1], r, t_min, closest, t)) { hit = true; closest = t; face = 2u; }
-    if (rt_rect_t(1u, b.p0[0], b.p1[0], b.p0[2], b.p1[2], b.p0[1], r, t_min, closest, t)) { hit = true; closest = t; face = 3u; }
-    if (rt_rect_t(2u, b.p0[1], b.p1[1], b.p0[2], b.p1[2], b.p1[0], r, t_min, closest, t)) { hit = true; closest = t; face = 4u; }
-    if (rt_rect_t(2u, b.p0[1], b.p1[1], b.p0[2], b.p1[2], b.p0[0], r, t_min, closest, t)) { hit = true; closest = t; face = 5u; }
+    if (rt_rect_axis_t<0>(b.p0[0], b.p1[0], b.p0[1], b.p1[1], b.p1[2], r, t_min, closest, t)) { hit = true; closest = t; face = 0u; }
+    if (rt_rect_axis_t<0>(b.p0[0], b.p1[0], b.p0[1], b.p1[1], b.p0[2], r, t_min, closest, t)) { hit = true; closest = t; face = 1u; }
+    if (rt_rect_axis_t<1>(b.p0[0], b.p1[0], b.p0[2], b.p1[2], b.p1[1], r, t_min, closest, t)) { hit = true; closest = t; face = 2u; }
+    if (rt_rect_axis_t<1>(b.p0[0], b.p1[0], b.p0[2], b.p1[2], b.p0[1], r, t_min, closest, t)) { hit = true; closest = t; face = 3u; }
+    if (rt_rect_axis_t<2>(b.p0[1], b.p1[1], b.p0[2], b.p1[2], b.p1[0], r, t_min, closest, t)) { hit = true; closest = t; face = 4u; }
+    if (rt_rect_axis_t<2>(b.p0[1], b.p1[1], b.p0[2], b.p1[2], b.p0[0], r, t_min, closest, t)) { hit = true; closest = t; face = 5u; }
     if (hit) t_out = closest;
     return hit;
 }
@@ -231,9 +241,16 @@ RT_HD bool rt_boundary_t(const DScene& sc, uint32_t ref, Ray r, double t_min, do
 // ConstantMedium::hit (constant_medium.rs:25-66). `xi` is the uniform the reference draws at :53.
 RT_HD bool rt_medium_t(const DScene& sc, const RtMedium& m, const Ray& r, double t_min, double t_max, double xi,
                        double& t_out) {
-    double t1, t2;
-    if (!rt_boundary_t(sc, m.boundary, r, -RT_INF, RT_INF, t1)) return false;
-    if (!rt_boundary_t(sc, m.boundary, r, t1 + 0.0001, RT_INF, t2)) return false;
+    double t1 = 0.0, t2 = 0.0;
+    {   // boundary.hit(r, -inf, inf) then boundary.hit(r, rec1.t + 0.0001, inf) (constant_medium.rs:29-34); written as a
+        // loop so that the boundary test is instantiated once
+        double lo = -RT_INF, t = 0.0;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            if (!rt_boundary_t(sc, m.boundary, r, lo, RT_INF, t)) return false;
+            if (pass == 0) { t1 = t; lo = t + 0.0001; } else t2 = t;
+        }
+    }
     if (t1 < t_min) t1 = t_min;
     if (t2 > t_max) t2 = t_max;
     if (t1 >= t2) return false;
