@@ -34,10 +34,13 @@
 #define RT_COUNTER_STRIDE 8u /* per iteration: [0] live paths entering it, [1+m] hits on material type m */
 
 // ---- device structures ------------------------------------------------------------------------------------
+// Path state, one record per path, each record one 64-byte line: once the live queue has been compacted the slots a
+// wave touches are scattered, and a scattered 8-byte access costs a whole line anyway.
+struct PathRay { double ox, oy, oz, dx, dy, dz, tm, pad; };            // current ray (ray.rs:5-9)
+struct PathAcc { double tr, tg, tb, rr, rg, rb, pad0, pad1; };         // throughput (product of attenuations, main.rs:70) and radiance
 struct PathBufs {
-    double *ox, *oy, *oz, *dx, *dy, *dz, *tm; // current ray (ray.rs:5-9)
-    double *tr, *tg, *tb;                     // throughput: product of attenuations so far (main.rs:70)
-    double *rr, *rg, *rb;                     // radiance of the sample
+    PathRay* ray;
+    PathAcc* acc;
     RtHitLite* hit;
 };
 struct PassInfo {
@@ -121,9 +124,11 @@ __device__ inline void block_append(const bool (&take)[R], const uint32_t (&slot
 
 __device__ inline Ray load_ray(const PathBufs& pb, uint32_t slot) {
     Ray r;
-    r.o = v3(pb.ox[slot], pb.oy[slot], pb.oz[slot]);
-    r.d = v3(pb.dx[slot], pb.dy[slot], pb.dz[slot]);
-    r.tm = pb.tm[slot];
+    const double2* q = (const double2*)(pb.ray + slot);
+    const double2 a = q[0], b = q[1], c = q[2], d = q[3];
+    r.o = v3(a.x, a.y, b.x);
+    r.d = v3(b.y, c.x, c.y);
+    r.tm = d.x;
     return r;
 }
 struct SlotRay { // the world-space ray of a path, re-read from the path buffers on demand
@@ -139,6 +144,13 @@ struct QueryRay {
         return r;
     }
 };
+__device__ inline void store_ray(const PathBufs& pb, uint32_t slot, const Ray& r) {
+    double2* q = (double2*)(pb.ray + slot);
+    q[0] = make_double2(r.o.x, r.o.y);
+    q[1] = make_double2(r.o.z, r.d.x);
+    q[2] = make_double2(r.d.y, r.d.z);
+    q[3] = make_double2(r.tm, 0.0);
+}
 __device__ inline Sampler slot_sampler(const PassInfo& pi, uint32_t slot, uint32_t bounce) {
     const uint32_t lp = slot / pi.S, s = slot - lp * pi.S;
     return sampler_make(pi.pixmap[lp], pi.sample_offset + s, bounce, pi.seed);
@@ -157,11 +169,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtCameraDev cam, PassInfo p
         const uint32_t y = pixel / pi.width, x = pixel - y * pi.width;
         const Sampler smp = sampler_make(pixel, pi.sample_offset + s, 0u, pi.seed);
         const Ray r = rt_primary_ray(cam, x, y, pi.width, pi.height, smp, pi.compat);
-        pb.ox[slot] = r.o.x; pb.oy[slot] = r.o.y; pb.oz[slot] = r.o.z;
-        pb.dx[slot] = r.d.x; pb.dy[slot] = r.d.y; pb.dz[slot] = r.d.z;
-        pb.tm[slot] = r.tm;
-        pb.tr[slot] = 1.0; pb.tg[slot] = 1.0; pb.tb[slot] = 1.0;
-        pb.rr[slot] = 0.0; pb.rg[slot] = 0.0; pb.rb[slot] = 0.0;
+        store_ray(pb, slot, r);
+        PathAcc acc;
+        acc.tr = 1.0; acc.tg = 1.0; acc.tb = 1.0; acc.rr = 0.0; acc.rg = 0.0; acc.rb = 0.0; acc.pad0 = 0.0; acc.pad1 = 0.0;
+        pb.acc[slot] = acc;
     }
 }
 
@@ -301,9 +312,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bin(DScene sc, PassInfo pi, PathBu
                 const RtHitLite h = pb.hit[slot[r]];
                 if (h.ref == RT_REF_NONE) { // main.rs:56-58: return background
                     const V3 bg = rt_background(pi.bg, pi.bg_mode, load_ray(pb, slot[r]));
-                    pb.rr[slot[r]] += pb.tr[slot[r]] * bg.x;
-                    pb.rg[slot[r]] += pb.tg[slot[r]] * bg.y;
-                    pb.rb[slot[r]] += pb.tb[slot[r]] * bg.z;
+                    PathAcc* acc = pb.acc + slot[r];
+                    acc->rr += acc->tr * bg.x;
+                    acc->rg += acc->tg * bg.y;
+                    acc->rb += acc->tb * bg.z;
                 } else {
                     uint32_t m;
                     const uint32_t ty = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
@@ -355,16 +367,17 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
             const Sampler smp = slot_sampler(pi, slot, it);
             const ShadeOut o = rt_shade(sc, m, r, rec, smp);
             if (MAT == RT_MAT_DIFFUSE_LIGHT) { // the only material whose emitted() is not black
-                pb.rr[slot] += pb.tr[slot] * o.emitted.x;
-                pb.rg[slot] += pb.tg[slot] * o.emitted.y;
-                pb.rb[slot] += pb.tb[slot] * o.emitted.z;
+                PathAcc* acc = pb.acc + slot;
+                acc->rr += acc->tr * o.emitted.x;
+                acc->rg += acc->tg * o.emitted.y;
+                acc->rb += acc->tb * o.emitted.z;
             }
             // a path that used its last bounce adds nothing more: ray_color(depth <= 0) is black (main.rs:52-54)
             if (o.did_scatter && it + 1u < pi.max_depth) {
                 alive = true;
-                pb.ox[slot] = o.scattered.o.x; pb.oy[slot] = o.scattered.o.y; pb.oz[slot] = o.scattered.o.z;
-                pb.dx[slot] = o.scattered.d.x; pb.dy[slot] = o.scattered.d.y; pb.dz[slot] = o.scattered.d.z;
-                pb.tr[slot] *= o.attenuation.x; pb.tg[slot] *= o.attenuation.y; pb.tb[slot] *= o.attenuation.z;
+                store_ray(pb, slot, o.scattered);
+                PathAcc* acc = pb.acc + slot;
+                acc->tr *= o.attenuation.x; acc->tg *= o.attenuation.y; acc->tb *= o.attenuation.z;
             }
         }
         const bool take[1] = {alive};
@@ -380,7 +393,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_accumulate(PassInfo pi, PathBufs p
         double r = sum[o], g = sum[o + 1], b = sum[o + 2];
         for (uint32_t s = 0; s < pi.S; ++s) {
             const uint32_t slot = lp * pi.S + s;
-            r += pb.rr[slot]; g += pb.rg[slot]; b += pb.rb[slot];
+            const PathAcc* acc = pb.acc + slot;
+            r += acc->rr; g += acc->rg; b += acc->rb;
         }
         sum[o] = r; sum[o + 1] = g; sum[o + 2] = b;
     }
@@ -456,7 +470,7 @@ struct rt_context {
     int n_cu = 256;
     // path pool
     size_t cap_paths = 0;
-    double* f64pool = nullptr; // 13 arrays of cap_paths
+    double* f64pool = nullptr; // cap_paths PathRay records, then cap_paths PathAcc records
     RtHitLite* hit = nullptr;
     uint32_t* u32pool = nullptr; // 2 live queues + 5 buckets, cap_paths each
     uint32_t* counters = nullptr;
@@ -536,7 +550,7 @@ int ensure_paths(rt_context* ctx, size_t paths, uint32_t max_depth) {
         if (ctx->hit) hipFree(ctx->hit);
         if (ctx->u32pool) hipFree(ctx->u32pool);
         ctx->f64pool = nullptr; ctx->hit = nullptr; ctx->u32pool = nullptr; ctx->cap_paths = 0;
-        RT_HIP(hipMalloc((void**)&ctx->f64pool, paths * 13 * sizeof(double)), "hipMalloc path state");
+        RT_HIP(hipMalloc((void**)&ctx->f64pool, paths * (sizeof(PathRay) + sizeof(PathAcc))), "hipMalloc path state");
         RT_HIP(hipMalloc((void**)&ctx->hit, paths * sizeof(RtHitLite)), "hipMalloc hit records");
         RT_HIP(hipMalloc((void**)&ctx->u32pool, paths * 7 * sizeof(uint32_t)), "hipMalloc queues");
         ctx->cap_paths = paths;
@@ -782,8 +796,8 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
     if (rc != RT_OK) return rc;
 
     PathBufs pb;
-    double** arr[13] = {&pb.ox, &pb.oy, &pb.oz, &pb.dx, &pb.dy, &pb.dz, &pb.tm, &pb.tr, &pb.tg, &pb.tb, &pb.rr, &pb.rg, &pb.rb};
-    for (int i = 0; i < 13; ++i) *arr[i] = ctx->f64pool + (size_t)i * ctx->cap_paths;
+    pb.ray = (PathRay*)ctx->f64pool;
+    pb.acc = (PathAcc*)(pb.ray + ctx->cap_paths);
     pb.hit = ctx->hit;
     QueueSet qs;
     qs.live[0] = ctx->u32pool;
