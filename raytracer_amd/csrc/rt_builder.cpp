@@ -203,6 +203,7 @@ int rt_builder::build_bvh_node(std::vector<BNode>& tree, std::vector<int>& objec
     n.box = surrounding_box(bl, br);
     n.left_node = left_node; n.right_node = right_node;
     n.left_obj = left_obj; n.right_obj = right_obj;
+    n.axis = axis;
     return me;
 }
 
@@ -350,7 +351,14 @@ uint32_t rt_builder::emit_bvh(Flat& f, const ObjRec& o, int node, int parent, ui
         r = emit(f, bn.right_obj, parent, depth, rneed);
         if (r == RT_REF_NONE) return RT_REF_NONE;
     }
-    f.nodes[me].left = l;
+    // A nearer-child-first order may only be offered where every box below really bounds its contents: with a box that
+    // does not (RotateY's), what the reference finds depends on the order it tests in. Measured on MI355X, ordering by
+    // the sort axis alone loses more than it gains on this kind of tree (median splits on random axes; one huge
+    // object - a ground sphere - sorts into the left child on two axes and ends most rays early when it is tested
+    // first): Book-2 scene -4 % traversal time, random-spheres scenes +20..45 %. So no axis is published and the
+    // traversal keeps the reference's left-then-right order everywhere.
+    const bool publish_axis = false;
+    f.nodes[me].left = l | (publish_axis && o.exact_bounds ? (uint32_t)(bn.axis + 1) << RT_REF_AUX_SHIFT : 0u);
     f.nodes[me].right = r;
     need = std::max(std::max(2u, 1u + lneed), rneed);
     return RT_MAKE_REF(RT_REF_NODE, me);
@@ -449,6 +457,9 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         }
         tree_ref = next;
     }
+    const size_t biggest = std::max({f.nodes.size(), f.spheres.size(), f.mspheres.size(), f.rects.size(), f.boxes.size(), f.media.size(),
+                                     f.insts.size(), f.list_entries.size()});
+    if (biggest > (size_t)RT_REF_INDEX_MASK) return fail(RT_ERR_UNSUPPORTED, "scene too large: %zu records of one kind, limit %u", biggest, RT_REF_INDEX_MASK);
     const uint32_t stack_need = std::max(1u, need) + 1u;
     if (stack_need > RT_STACK_CAP)
         return fail(RT_ERR_UNSUPPORTED, "scene needs a traversal stack of %u entries, capacity is %u", stack_need, RT_STACK_CAP);
@@ -691,6 +702,7 @@ int rt_translate(rt_builder* b, int child, const double off[3]) {
     if (!b) return RT_ERR_INVALID;
     if (!off || !b->valid_obj(child)) return b->fail(RT_ERR_INVALID, "translate: bad argument");
     ObjRec o; o.kind = OBJ_TRANSLATE; o.child = child; o.d[0] = off[0]; o.d[1] = off[1]; o.d[2] = off[2];
+    o.exact_bounds = b->objs[child].exact_bounds;
     int id = b->add_obj(o);
     append_fmt(b->log, "translate %d %d %a %a %a\n", id, child, off[0], off[1], off[2]);
     return id;
@@ -699,6 +711,7 @@ int rt_rotate_y(rt_builder* b, int child, double angle) {
     if (!b) return RT_ERR_INVALID;
     if (!b->valid_obj(child)) return b->fail(RT_ERR_INVALID, "rotate_y: bad child handle %d", child);
     ObjRec o; o.kind = OBJ_ROTATE_Y; o.child = child;
+    o.exact_bounds = (b->flags & RT_BLOB_FLAG_BOOK_BBOX) != 0 && b->objs[child].exact_bounds;
     const double radians = angle * RT_PI / 180.0; // rtweekend.rs:5-7
     o.d[0] = std::sin(radians); o.d[1] = std::cos(radians); o.d[2] = 0.0;
     // RotateY::new (hittable.rs:104-144): bbox = the child's box at times (0,1); the rotated min/max
@@ -729,6 +742,7 @@ int rt_constant_medium(rt_builder* b, int boundary, double density, double r, do
     b->texs.push_back(t);
     int mat = add_mat(b, RT_MAT_ISOTROPIC, (int)b->texs.size() - 1, 0, 0, 0, 0);
     ObjRec o; o.kind = OBJ_MEDIUM; o.child = boundary; o.mat = mat; o.d[0] = -1.0 / density;
+    o.exact_bounds = b->objs[boundary].exact_bounds;
     o.medium_index = b->n_media++;
     int id = b->add_obj(o);
     append_fmt(b->log, "constant_medium %d %d %a %a %a %a %d %d\n", id, boundary, density, r, g, bl, mat, (int)b->texs.size() - 1);
@@ -737,6 +751,7 @@ int rt_constant_medium(rt_builder* b, int boundary, double density, double r, do
 int rt_list_new(rt_builder* b) {
     if (!b) return RT_ERR_INVALID;
     ObjRec o; o.kind = OBJ_LIST;
+    o.exact_bounds = false;
     int id = b->add_obj(o);
     append_fmt(b->log, "list %d\n", id);
     return id;
@@ -765,6 +780,7 @@ int rt_bvh(rt_builder* b, int list, double t0, double t1) {
     b->axis_log.clear();
     if (b->build_bvh_node(o.tree, objects, keys, 0, objects.size(), t0, t1) < 0) return RT_ERR_PANIC;
     o.box = o.tree[0].box;
+    for (int m : objects) o.exact_bounds = o.exact_bounds && b->objs[m].exact_bounds;
     int id = b->add_obj(std::move(o));
     // the axes drawn (bvh.rs:22), in construction order, so that a replay can rebuild the same tree
     append_fmt(b->log, "bvh %d %d %a %a ", id, list, t0, t1);

@@ -30,6 +30,7 @@ enum ObjKind { OBJ_SPHERE, OBJ_MSPHERE, OBJ_XYRECT, OBJ_XZRECT, OBJ_YZRECT, OBJ_
 struct BNode { // BvhNode (bvh.rs:8-12): each side is another node or an object handle
     AABB box;
     int left_node = -1, right_node = -1, left_obj = -1, right_obj = -1;
+    int axis = 0; // the axis drawn at bvh.rs:22: children are ordered by their boxes' minimum on it
 };
 
 struct ObjRec {
@@ -42,6 +43,9 @@ struct ObjRec {
     AABB box = {{0, 0, 0}, {0, 0, 0}}; // RotateY::bbox / BvhNode::_box
     bool hasbox = true;        // RotateY::hasbox
     int medium_index = -1;
+    // bounding_box() really contains the object. False for RotateY (keeps the child's unrotated box, hittable.rs:115-143)
+    // and HittableList (last member's box only, hittable_list.rs:55-75) and whatever is built on them.
+    bool exact_bounds = true;
 };
 struct MatRec {
     uint32_t type = 0;

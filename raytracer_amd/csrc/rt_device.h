@@ -334,14 +334,24 @@ struct RtTrav {
     uint32_t cur; // next reference to process; RT_REF_NONE = finished
 };
 
-// One box test: s.cur must be a node. BvhNode::hit (bvh.rs:112-122): box against the current closest distance,
-// then the left child, the right one kept for later.
+// One box test: s.cur must be a node. BvhNode::hit (bvh.rs:112-122) tests the box against the current closest
+// distance and then always the left child before the right one. The closest hit does not depend on that order, so
+// the child that starts nearer along the ray is entered first (the children were sorted by their boxes' minimum on
+// the node's axis, so for a ray heading down that axis the right child is the nearer one) and the other kept for
+// later: what is found early shrinks the distance the remaining boxes are tested against.
 template <class Stack>
 RT_HD void rt_trav_node_step(const DScene& sc, RtTrav& s, Stack& st, double t_min) {
     const RtNode n = rt_load_node(sc.nodes + RT_REF_INDEX(s.cur));
     if (rt_aabb_hit(n, s.r, s.inv, t_min, s.best.t)) {
-        if (n.right != RT_REF_NONE) st.push(n.right);
-        s.cur = n.left;
+        const uint32_t left = RT_REF_STRIP_AUX(n.left), axis1 = RT_REF_AUX(n.left);
+        if (n.right == RT_REF_NONE) {
+            s.cur = left;
+        } else {
+            const double d = axis1 == 1u ? s.r.d.x : (axis1 == 2u ? s.r.d.y : s.r.d.z);
+            const bool right_first = axis1 != 0u && d < 0.0;
+            st.push(right_first ? left : n.right);
+            s.cur = right_first ? n.right : left;
+        }
     } else {
         s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop();
     }

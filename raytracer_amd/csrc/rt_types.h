@@ -10,7 +10,7 @@
 #include <stdint.h>
 
 #define RT_BLOB_MAGIC 0x31425452u /* "RTB1" little endian */
-#define RT_BLOB_VERSION 5u
+#define RT_BLOB_VERSION 6u
 
 // ---- tagged references -------------------------------------------------------------------------
 enum RtRefType : uint32_t {
@@ -25,11 +25,16 @@ enum RtRefType : uint32_t {
     RT_REF_LIST = 8,     // HittableList: index of its first entry in the NONE-terminated entry array
     RT_REF_POP = 9       // traversal-internal marker: leave instance `index`
 };
+// layout: type[31:28] | aux[27:26] | index[25:0]. aux is used in one place only: in a node's `left` it holds
+// 1 + the axis the node's children were sorted on (bvh.rs:22-27), 0 = unknown.
 #define RT_REF_SHIFT 28u
-#define RT_REF_INDEX_MASK 0x0FFFFFFFu
+#define RT_REF_INDEX_MASK 0x03FFFFFFu
+#define RT_REF_AUX_SHIFT 26u
 #define RT_MAKE_REF(type, index) ((((uint32_t)(type)) << RT_REF_SHIFT) | ((uint32_t)(index)&RT_REF_INDEX_MASK))
 #define RT_REF_TYPE(ref) ((uint32_t)(ref) >> RT_REF_SHIFT)
 #define RT_REF_INDEX(ref) ((uint32_t)(ref)&RT_REF_INDEX_MASK)
+#define RT_REF_AUX(ref) (((uint32_t)(ref) >> RT_REF_AUX_SHIFT) & 3u)
+#define RT_REF_STRIP_AUX(ref) ((uint32_t)(ref) & ~(3u << RT_REF_AUX_SHIFT))
 
 #define RT_NO_PARENT (-1)
 #define RT_MAX_CHAIN 4   /* deepest Translate/RotateY nesting above any primitive */
@@ -39,6 +44,7 @@ enum RtRefType : uint32_t {
 // 32-byte BVH node, nodes of one tree stored in depth-first pre-order (a node's left subtree follows
 // it immediately). `left`/`right` are refs: another node, or the object the reference would store
 // in that Arc. A span-1 node (bvh.rs:33-35, same object on both sides) carries right = NONE.
+// The aux bits of `left` record the sort axis, so a traversal may enter the nearer child first.
 struct RtNode {
     float lo[3];
     float hi[3];

@@ -108,11 +108,11 @@ def test_blob_layout_of_the_book2_final_scene():
     assert all(off % 256 == 0 for off, _ in s.values())
     assert 2 <= h["stack_need"] <= 40
     # world list: 11 entries then the terminator
-    world_first = h["world"] & 0x0FFFFFFF
+    world_first = h["world"] & 0x03FFFFFF
     entries = np.frombuffer(blob, dtype="<u4", count=s["list_entries"][1], offset=s["list_entries"][0])
     assert (h["world"] >> 28) == 8 and np.count_nonzero(entries[world_first:world_first + 11]) == 11 and entries[world_first + 11] == 0
     # the 9 entries that are primitives / media, as a list of their own
-    flat_first = h["world_flat"] & 0x0FFFFFFF
+    flat_first = h["world_flat"] & 0x03FFFFFF
     flat = entries[flat_first:flat_first + 10]
     assert (h["world_flat"] >> 28) == 8 and np.count_nonzero(flat[:9]) == 9 and flat[9] == 0
     assert set(flat[:9].tolist()) <= set(entries[world_first:world_first + 11].tolist())
@@ -120,9 +120,9 @@ def test_blob_layout_of_the_book2_final_scene():
     nodes = np.frombuffer(blob, dtype=np.dtype([("lo", "<f4", 3), ("hi", "<f4", 3), ("left", "<u4"), ("right", "<u4")]),
                           count=s["nodes"][1], offset=s["nodes"][0])
     assert (h["world_tree"] >> 28) == 1
-    top = nodes[h["world_tree"] & 0x0FFFFFFF]
-    assert top["left"] == (1 << 28) | 0 and (top["right"] >> 28) == 1
-    wrap = nodes[top["right"] & 0x0FFFFFFF]
+    top = nodes[h["world_tree"] & 0x03FFFFFF]
+    assert top["left"] == (1 << 28) | 0 and (top["right"] >> 28) == 1      # added nodes carry no sort axis
+    wrap = nodes[top["right"] & 0x03FFFFFF]
     assert (wrap["left"] >> 28) == 7 and wrap["right"] == 0
     # the instanced cluster: spheres r=10 with centres in [0,165)^3, rotated 15 degrees about y, moved by (-100,270,395)
     assert np.all(wrap["lo"] < [-100, 265, 345]) and np.all(wrap["hi"] > [60, 430, 540])
@@ -134,6 +134,9 @@ def test_cornell_has_seven_nodes_and_f32_bounds_contain_the_f64_boxes():
     b, info, blob, _ = util.build_scene("cornell_box")
     h = header(blob)
     assert h["sections"]["nodes"][1] == 7 and h["world_tree"] == (1 << 28) | 0 and h["world_flat"] == 0
+    # its RotateY instances keep unrotated boxes: no node may offer a traversal order other than the reference's
+    cn = np.frombuffer(blob, dtype="<u4", count=7 * 8, offset=h["sections"]["nodes"][0]).reshape(7, 8)
+    assert np.all((cn[:, 6] >> 26) & 3 == 0)
     assert h["sections"]["rects"][1] == 6 and h["sections"]["boxes"][1] == 2
     # a BVH over known spheres: every node's f32 box must contain the exact f64 union of its subtree
     rng = np.random.default_rng(3)
@@ -151,12 +154,13 @@ def test_cornell_has_seven_nodes_and_f32_bounds_contain_the_f64_boxes():
     assert cnt == 2 * 256 - 1 + 0 or cnt >= 257 // 2    # one node per internal split plus span-1/2 leaves
 
     def bounds(ref):
-        ty, idx = ref >> 28, ref & 0x0FFFFFFF
+        ty, idx = ref >> 28, ref & 0x03FFFFFF
         if ty == 2:
             return sph[idx, :3] - sph[idx, 3], sph[idx, :3] + sph[idx, 3]
         assert ty == 1
         n = nodes[idx]
-        lo, hi = bounds(int(n["left"]))
+        assert (int(n["left"]) >> 26) & 3 == 0                                  # no sort axis published
+        lo, hi = bounds(int(n["left"]) & ~(3 << 26))
         if n["right"]:
             lo2, hi2 = bounds(int(n["right"]))
             lo, hi = np.minimum(lo, lo2), np.maximum(hi, hi2)
@@ -168,7 +172,7 @@ def test_cornell_has_seven_nodes_and_f32_bounds_contain_the_f64_boxes():
     # depth-first pre-order: a node's left child, when it is a node, is the next record
     for i, n in enumerate(nodes):
         if n["left"] >> 28 == 1:
-            assert (n["left"] & 0x0FFFFFFF) == i + 1
+            assert (n["left"] & 0x03FFFFFF) == i + 1
 
 
 def test_description_log_replays_to_the_same_scene_twice():
