@@ -35,6 +35,7 @@ void append_fmt(std::string& s, const char* fmt, ...) {
     if (n > 0) s.append(buf, (size_t)std::min<int>(n, (int)sizeof buf - 1));
 }
 
+// f32 bounds that contain the f64 value: equal to it when it is representable, else the next f32 outward.
 float round_down_f32(double v) {
     float f = (float)v;
     if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());

@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_extend_tree(DScene sc, PassInfo pi
                 if (i < n && i < chunk_end) {
                     slot = live ? live[i] : i;
                     s.r = load_ray(pb, slot);
-                    s.inv = rt_inv_dir(s.r);
+                    s.slab = rt_slab_of(s.r);
                     if (seeded) {
                         const RtHitLite h = pb.hit[slot];
                         s.best.t = h.t; s.best.ref = h.ref; s.best.aux = h.aux;
@@ -363,9 +363,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
             else if (ty == RT_REF_BOX) mi = sc.box_meta[idx].material;
             else mi = sc.media[idx].material;
             const RtMaterial m = sc.materials[mi];
-            const HitRec rec = rt_reconstruct(sc, r, h, rt_material_reads_uv(sc, m));
+            const bool uv = (MAT == RT_MAT_METAL || MAT == RT_MAT_DIELECTRIC) ? false : rt_material_reads_uv(sc, m);
+            const HitRec rec = rt_reconstruct(sc, r, h, uv);
             const Sampler smp = slot_sampler(pi, slot, it);
-            const ShadeOut o = rt_shade(sc, m, r, rec, smp);
+            const ShadeOut o = rt_shade_as<MAT>(sc, m, r, rec, smp);
             if (MAT == RT_MAT_DIFFUSE_LIGHT) { // the only material whose emitted() is not black
                 PathAcc* acc = pb.acc + slot;
                 acc->rr += acc->tr * o.emitted.x;
