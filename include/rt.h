@@ -41,7 +41,12 @@ rt_builder* rt_builder_new(uint64_t seed);
 void rt_builder_free(rt_builder*);
 const char* rt_builder_last_error(const rt_builder*);
 /* flags: bit 0 = RotateY keeps its rotated bounding box (book behaviour) instead of discarding it
- * (hittable.rs:117-143). Default 0 = as the reference. Set before creating RotateY objects. */
+ * (hittable.rs:117-143); set before creating RotateY objects.
+ * bit 1 = every BvhNode keeps the topology BvhNode::new builds (random axis, median split, bvh.rs:15-66). Without
+ * it, a BvhNode whose boxes all bound their contents is compiled into a surface-area-heuristic tree over the same
+ * objects: closest hits are the same, fewer boxes are tested. Trees with a box that does not bound its contents
+ * (anything over the reference's RotateY) always keep the reference's topology and test order.
+ * Default 0. */
 int rt_builder_set_flags(rt_builder*, uint32_t flags);
 
 /* Texture (texture.rs:8-10) */

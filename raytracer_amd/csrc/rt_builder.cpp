@@ -324,44 +324,235 @@ uint32_t rt_builder::emit(Flat& f, int h, int parent, uint32_t depth, uint32_t& 
         return RT_MAKE_REF(RT_REF_LIST, first);
     }
     case OBJ_BVH: {
-        uint32_t r = emit_bvh(f, o, 0, parent, depth, need);
-        return r;
+        return emit_bvh(f, o, parent, depth, need);
     }
     }
     fail(RT_ERR_INVALID, "object %d: unknown kind", h);
     return RT_REF_NONE;
 }
 
-uint32_t rt_builder::emit_bvh(Flat& f, const ObjRec& o, int node, int parent, uint32_t depth, uint32_t& need) {
+// ---- BVH emission ---------------------------------------------------------------------------------------------
+namespace {
+const float kInfF = std::numeric_limits<float>::infinity();
+void set_box(float (&lo)[3], float (&hi)[3], const AABB& b) {
+    for (int i = 0; i < 3; ++i) { lo[i] = round_down_f32(b.lo[i]); hi[i] = round_up_f32(b.hi[i]); }
+}
+void set_box_empty(float (&lo)[3], float (&hi)[3]) { for (int i = 0; i < 3; ++i) { lo[i] = kInfF; hi[i] = -kInfF; } }
+void set_box_all(float (&lo)[3], float (&hi)[3]) { for (int i = 0; i < 3; ++i) { lo[i] = -kInfF; hi[i] = kInfF; } }
+RtNode blank_node() {
+    RtNode n;
+    set_box_empty(n.lo0, n.hi0); set_box_empty(n.lo1, n.hi1);
+    n.c0 = n.c1 = RT_REF_NONE; n.pad[0] = n.pad[1] = 0u;
+    return n;
+}
+AABB box_union(const AABB& a, const AABB& b) {
+    AABB o;
+    for (int i = 0; i < 3; ++i) { o.lo[i] = std::min(a.lo[i], b.lo[i]); o.hi[i] = std::max(a.hi[i], b.hi[i]); }
+    return o;
+}
+double half_area(const AABB& b) {
+    const double x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
+    return x * y + y * z + z * x;
+}
+const AABB kEmptyBox = {{kInf, kInf, kInf}, {-kInf, -kInf, -kInf}};
+
+// A binary tree over object handles, independent of how it was built.
+struct Kid { int node = -1, obj = -1; AABB box = kEmptyBox; }; // node >= 0: TNode index; else obj >= 0: object; else absent
+struct TNode { Kid kid[2]; };
+struct SahItem { int obj; AABB box; double c[3]; };
+
+const int kSweepMax = 128; // at most this many objects: exact sweep over sorted centroids; more: 32 bins per axis
+const int kBins = 32;
+const int kMaxTreeDepth = 30;
+
+int ceil_log2(size_t n) { int k = 0; while (((size_t)1 << k) < n) ++k; return k; }
+
+// Top-down surface-area-heuristic build, one object per leaf. Cost of a split = area(L) * |L| + area(R) * |R|.
+Kid build_sah(std::vector<TNode>& tree, std::vector<SahItem>& items, size_t start, size_t end, int depth) {
+    Kid k;
+    const size_t n = end - start;
+    if (n == 1) { k.obj = items[start].obj; k.box = items[start].box; return k; }
+    size_t mid = start + n / 2;
+    AABB cb = kEmptyBox;
+    for (size_t i = start; i < end; ++i)
+        for (int a = 0; a < 3; ++a) { cb.lo[a] = std::min(cb.lo[a], items[i].c[a]); cb.hi[a] = std::max(cb.hi[a], items[i].c[a]); }
+    int widest = 0;
+    for (int a = 1; a < 3; ++a) if (cb.hi[a] - cb.lo[a] > cb.hi[widest] - cb.lo[widest]) widest = a;
+    const bool degenerate = !(cb.hi[widest] - cb.lo[widest] > 0.0);
+    const bool balanced_only = depth + ceil_log2(n) >= kMaxTreeDepth; // keep the traversal stack within its capacity
+    auto median_on = [&](int axis) {
+        std::nth_element(items.begin() + (long)start, items.begin() + (long)mid, items.begin() + (long)end,
+                         [axis](const SahItem& x, const SahItem& y) { return x.c[axis] < y.c[axis]; });
+    };
+    if (n == 2 || degenerate) {
+        // nothing to choose
+    } else if (balanced_only) {
+        median_on(widest);
+    } else if (n <= (size_t)kSweepMax) {
+        double best = kInf; int best_axis = -1; size_t best_cut = 0;
+        std::vector<double> right_area(n);
+        for (int a = 0; a < 3; ++a) {
+            if (!(cb.hi[a] - cb.lo[a] > 0.0)) continue;
+            std::sort(items.begin() + (long)start, items.begin() + (long)end,
+                      [a](const SahItem& x, const SahItem& y) { return x.c[a] < y.c[a]; });
+            AABB acc = kEmptyBox;
+            for (size_t i = n; i-- > 1;) { acc = box_union(acc, items[start + i].box); right_area[i] = half_area(acc); }
+            acc = kEmptyBox;
+            for (size_t i = 1; i < n; ++i) {
+                acc = box_union(acc, items[start + i - 1].box);
+                const double cost = half_area(acc) * (double)i + right_area[i] * (double)(n - i);
+                if (cost < best) { best = cost; best_axis = a; best_cut = i; }
+            }
+        }
+        if (best_axis >= 0) {
+            std::sort(items.begin() + (long)start, items.begin() + (long)end,
+                      [best_axis](const SahItem& x, const SahItem& y) { return x.c[best_axis] < y.c[best_axis]; });
+            mid = start + best_cut;
+        } else median_on(widest);
+    } else {
+        double best = kInf; int best_axis = -1, best_bin = 0;
+        for (int a = 0; a < 3; ++a) {
+            const double ext = cb.hi[a] - cb.lo[a];
+            if (!(ext > 0.0)) continue;
+            AABB bb[kBins]; size_t cnt[kBins];
+            for (int i = 0; i < kBins; ++i) { bb[i] = kEmptyBox; cnt[i] = 0; }
+            const double scale = (double)kBins / ext;
+            for (size_t i = start; i < end; ++i) {
+                int bi = (int)((items[i].c[a] - cb.lo[a]) * scale);
+                bi = std::min(kBins - 1, std::max(0, bi));
+                bb[bi] = box_union(bb[bi], items[i].box); ++cnt[bi];
+            }
+            double ra[kBins]; size_t rc[kBins];
+            AABB acc = kEmptyBox; size_t c = 0;
+            for (int i = kBins - 1; i >= 1; --i) { acc = box_union(acc, bb[i]); c += cnt[i]; ra[i] = c ? half_area(acc) : 0.0; rc[i] = c; }
+            acc = kEmptyBox; c = 0;
+            for (int i = 1; i < kBins; ++i) {
+                acc = box_union(acc, bb[i - 1]); c += cnt[i - 1];
+                if (c == 0 || rc[i] == 0) continue;
+                const double cost = half_area(acc) * (double)c + ra[i] * (double)rc[i];
+                if (cost < best) { best = cost; best_axis = a; best_bin = i; }
+            }
+        }
+        if (best_axis >= 0) {
+            const int a = best_axis;
+            const double scale = (double)kBins / (cb.hi[a] - cb.lo[a]), lo = cb.lo[a];
+            auto it = std::partition(items.begin() + (long)start, items.begin() + (long)end, [&](const SahItem& x) {
+                int bi = (int)((x.c[a] - lo) * scale);
+                bi = std::min(kBins - 1, std::max(0, bi));
+                return bi < best_bin;
+            });
+            mid = (size_t)(it - items.begin());
+            if (mid == start || mid == end) { mid = start + n / 2; median_on(widest); }
+        } else median_on(widest);
+    }
+    const int me = (int)tree.size();
+    tree.push_back(TNode());
+    const Kid a = build_sah(tree, items, start, mid, depth + 1);
+    const Kid b = build_sah(tree, items, mid, end, depth + 1);
+    tree[(size_t)me].kid[0] = a; tree[(size_t)me].kid[1] = b;
+    k.node = me; k.box = box_union(a.box, b.box);
+    return k;
+}
+}
+
+// A tree whose boxes all bound their contents: real boxes on both children, walked nearest first.
+static uint32_t emit_ordered(rt_builder* b, rt_builder::Flat& f, const std::vector<TNode>& tree, const Kid& k, int parent,
+                             uint32_t depth, uint32_t& need);
+
+uint32_t rt_builder::emit_bvh(Flat& f, const ObjRec& o, int parent, uint32_t depth, uint32_t& need) {
+    if (o.exact_bounds) {
+        std::vector<TNode> tree;
+        Kid root;
+        if (flags & RT_BLOB_FLAG_REFERENCE_TREE) {
+            // the reference's topology (bvh.rs:15-66); a span-1 node (bvh.rs:33-35) holds its object once
+            tree.resize(o.tree.size());
+            for (size_t i = 0; i < o.tree.size(); ++i) {
+                const BNode& bn = o.tree[i];
+                Kid l, r;
+                if (bn.left_node >= 0) { l.node = bn.left_node; l.box = o.tree[(size_t)bn.left_node].box; }
+                else { l.obj = bn.left_obj; if (!bounding_box(bn.left_obj, o.d[0], o.d[1], l.box)) return RT_REF_NONE; }
+                if (bn.right_node >= 0) { r.node = bn.right_node; r.box = o.tree[(size_t)bn.right_node].box; }
+                else if (bn.right_obj != bn.left_obj) { r.obj = bn.right_obj; if (!bounding_box(bn.right_obj, o.d[0], o.d[1], r.box)) return RT_REF_NONE; }
+                tree[i].kid[0] = l; tree[i].kid[1] = r;
+            }
+            root.node = 0; root.box = o.box;
+        } else {
+            std::vector<SahItem> items;
+            for (int m : objs[o.child].members) {
+                SahItem it;
+                it.obj = m;
+                if (!bounding_box(m, o.d[0], o.d[1], it.box)) { fail(RT_ERR_PANIC, "No bounding box"); return RT_REF_NONE; }
+                for (int a = 0; a < 3; ++a) it.c[a] = 0.5 * (it.box.lo[a] + it.box.hi[a]);
+                items.push_back(it);
+            }
+            root = build_sah(tree, items, 0, items.size(), 0);
+        }
+        return emit_ordered(this, f, tree, root, parent, depth, need);
+    }
+    // Replay form: the root's own box first (bvh.rs:113), in front of the root node.
+    const uint32_t gate = (uint32_t)f.nodes.size();
+    f.nodes.push_back(blank_node());
+    const uint32_t r = emit_replay(f, o, 0, parent, depth, need);
+    if (r == RT_REF_NONE) return RT_REF_NONE;
+    set_box(f.nodes[gate].lo0, f.nodes[gate].hi0, o.tree[0].box);
+    f.nodes[gate].c0 = r;
+    return RT_MAKE_REF(RT_REF_NODE, gate);
+}
+
+static uint32_t emit_ordered(rt_builder* b, rt_builder::Flat& f, const std::vector<TNode>& tree, const Kid& k, int parent,
+                             uint32_t depth, uint32_t& need) {
+    need = 0;
+    if (k.node < 0) return k.obj >= 0 ? b->emit(f, k.obj, parent, depth, need) : (uint32_t)RT_REF_NONE;
+    const uint32_t me = (uint32_t)f.nodes.size();
+    f.nodes.push_back(blank_node());
+    const TNode& t = tree[(size_t)k.node];
+    uint32_t n0 = 0, n1 = 0;
+    const uint32_t c0 = emit_ordered(b, f, tree, t.kid[0], parent, depth, n0);
+    if (c0 == RT_REF_NONE) return RT_REF_NONE;
+    uint32_t c1 = RT_REF_NONE;
+    if (t.kid[1].node >= 0 || t.kid[1].obj >= 0) {
+        c1 = emit_ordered(b, f, tree, t.kid[1], parent, depth, n1);
+        if (c1 == RT_REF_NONE) return RT_REF_NONE;
+    }
+    RtNode& n = f.nodes[me];
+    set_box(n.lo0, n.hi0, t.kid[0].box); n.c0 = c0;
+    if (c1 != RT_REF_NONE) { set_box(n.lo1, n.hi1, t.kid[1].box); n.c1 = c1; }
+    need = 1u + std::max(n0, n1); // either child may be entered first, the other one waits on the stack
+    return RT_MAKE_REF(RT_REF_NODE, me);
+}
+
+// A tree with a box that does not bound its contents: BvhNode `node` of the reference's tree in a form that makes
+// the traversal test exactly the boxes BvhNode::hit tests, in its order, against the same t_max (bvh.rs:112-122):
+//   child 0 = the left side with its own box (an object directly: the infinite box, hit() of an object tests no box);
+//   child 1 = the infinite box in front of a one-child node that holds the right side's box - tested when it is
+//             taken from the stack, after the left subtree - or the right object itself.
+uint32_t rt_builder::emit_replay(Flat& f, const ObjRec& o, int node, int parent, uint32_t depth, uint32_t& need) {
     const BNode& bn = o.tree[(size_t)node];
     const uint32_t me = (uint32_t)f.nodes.size();
-    RtNode n;
-    for (int i = 0; i < 3; ++i) { n.lo[i] = round_down_f32(bn.box.lo[i]); n.hi[i] = round_up_f32(bn.box.hi[i]); }
-    n.left = n.right = RT_REF_NONE;
-    f.nodes.push_back(n);
-    uint32_t lneed = 0, rneed = 0, l, r = RT_REF_NONE;
-    if (bn.left_node >= 0) l = emit_bvh(f, o, bn.left_node, parent, depth, lneed);
-    else l = emit(f, bn.left_obj, parent, depth, lneed);
-    if (l == RT_REF_NONE) return RT_REF_NONE;
+    f.nodes.push_back(blank_node());
+    uint32_t n0 = 0, n1 = 0, c0, c1 = RT_REF_NONE;
+    if (bn.left_node >= 0) c0 = emit_replay(f, o, bn.left_node, parent, depth, n0);
+    else c0 = emit(f, bn.left_obj, parent, depth, n0);
+    if (c0 == RT_REF_NONE) return RT_REF_NONE;
+    if (bn.left_node >= 0) set_box(f.nodes[me].lo0, f.nodes[me].hi0, o.tree[(size_t)bn.left_node].box);
+    else set_box_all(f.nodes[me].lo0, f.nodes[me].hi0);
+    f.nodes[me].c0 = c0;
     if (bn.right_node >= 0) {
-        r = emit_bvh(f, o, bn.right_node, parent, depth, rneed);
+        const uint32_t gate = (uint32_t)f.nodes.size();
+        f.nodes.push_back(blank_node());
+        const uint32_t r = emit_replay(f, o, bn.right_node, parent, depth, n1);
         if (r == RT_REF_NONE) return RT_REF_NONE;
+        set_box(f.nodes[gate].lo0, f.nodes[gate].hi0, o.tree[(size_t)bn.right_node].box);
+        f.nodes[gate].c0 = r;
+        c1 = RT_MAKE_REF(RT_REF_NODE, gate);
     } else if (bn.right_obj != bn.left_obj || objs[bn.right_obj].kind == OBJ_MEDIUM) {
         // span-1 nodes (bvh.rs:33-35) hold the same object twice; the second test can never win for a
         // surface, so it is dropped. A medium keeps both tests.
-        r = emit(f, bn.right_obj, parent, depth, rneed);
-        if (r == RT_REF_NONE) return RT_REF_NONE;
+        c1 = emit(f, bn.right_obj, parent, depth, n1);
+        if (c1 == RT_REF_NONE) return RT_REF_NONE;
     }
-    // A nearer-child-first order may only be offered where every box below really bounds its contents: with a box that
-    // does not (RotateY's), what the reference finds depends on the order it tests in. Measured on MI355X, ordering by
-    // the sort axis alone loses more than it gains on this kind of tree (median splits on random axes; one huge
-    // object - a ground sphere - sorts into the left child on two axes and ends most rays early when it is tested
-    // first): Book-2 scene -4 % traversal time, random-spheres scenes +20..45 %. So no axis is published and the
-    // traversal keeps the reference's left-then-right order everywhere.
-    const bool publish_axis = false;
-    f.nodes[me].left = l | (publish_axis && o.exact_bounds ? (uint32_t)(bn.axis + 1) << RT_REF_AUX_SHIFT : 0u);
-    f.nodes[me].right = r;
-    need = std::max(std::max(2u, 1u + lneed), rneed);
+    if (c1 != RT_REF_NONE) { set_box_all(f.nodes[me].lo1, f.nodes[me].hi1); f.nodes[me].c1 = c1; }
+    need = std::max(1u + n0, n1);
     return RT_MAKE_REF(RT_REF_NODE, me);
 }
 
@@ -398,7 +589,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     // The closest hit does not depend on the order in which the world's entries are tested (only exact ties do), so the
     // kernels test the entries that are plain primitives or media first, in lock step, and then walk the rest per lane.
     // The rest (BvhNodes, possibly under Translate/RotateY, nested lists) is hung under a chain of extra nodes
-    //     T_k = { box: union of the world-space bounds of entries k.., left: entry k, right: T_k+1 }
+    //     T_k = { child 0: entry k under its world-space bound, child 1: T_k+1 under the union of the bounds of entries k+1.. }
     // so that per-lane work is box tests only: an entry whose world-space bound the ray misses costs one box test
     // instead of an instance entry/exit. The extra boxes are supersets of what the entry's own root box admits (with
     // a 1e-6 relative margin against the rounding of the frame change), so they never cull a hit the reference finds.
@@ -423,11 +614,11 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         f.list_entries.push_back(RT_REF_NONE);
     }
     if (!tree_refs.empty()) {
-        const float inf = std::numeric_limits<float>::infinity();
-        std::vector<RtNode> bounds(tree_refs.size());
+        struct FBox { float lo[3], hi[3]; };
+        std::vector<FBox> bounds(tree_refs.size());
         for (size_t k = 0; k < tree_refs.size(); ++k) {
             AABB wb;
-            RtNode& n = bounds[k];
+            FBox& n = bounds[k];
             if (world_bound(tree_handles[k], wb)) {
                 for (int c = 0; c < 3; ++c) {
                     const double m = 1e-6 * std::max(std::max(std::fabs(wb.lo[c]), std::fabs(wb.hi[c])), wb.hi[c] - wb.lo[c]) + 1e-9;
@@ -435,26 +626,24 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
                     n.hi[c] = round_up_f32(wb.hi[c] + m);
                 }
             } else {
-                for (int c = 0; c < 3; ++c) { n.lo[c] = -inf; n.hi[c] = inf; }
+                set_box_all(n.lo, n.hi);
             }
         }
         // built back to front so that T_k can point at T_k+1
         uint32_t next = RT_REF_NONE;
-        RtNode acc = bounds.back();
+        FBox acc;
+        set_box_empty(acc.lo, acc.hi);
         for (size_t k = tree_refs.size(); k-- > 0;) {
-            for (int c = 0; c < 3; ++c) { acc.lo[c] = std::min(acc.lo[c], bounds[k].lo[c]); acc.hi[c] = std::max(acc.hi[c], bounds[k].hi[c]); }
-            uint32_t entry = tree_refs[k];
-            if (RT_REF_TYPE(entry) != RT_REF_NODE) { // give an instance / list its own box in front
-                RtNode w = bounds[k];
-                w.left = entry; w.right = RT_REF_NONE;
-                f.nodes.push_back(w);
-                entry = RT_MAKE_REF(RT_REF_NODE, f.nodes.size() - 1);
+            RtNode t = blank_node();
+            for (int c = 0; c < 3; ++c) { t.lo0[c] = bounds[k].lo[c]; t.hi0[c] = bounds[k].hi[c]; }
+            t.c0 = tree_refs[k];
+            if (next != RT_REF_NONE) {
+                for (int c = 0; c < 3; ++c) { t.lo1[c] = acc.lo[c]; t.hi1[c] = acc.hi[c]; }
+                t.c1 = next;
             }
-            if (next == RT_REF_NONE) { next = entry; continue; }
-            RtNode t = acc;
-            t.left = entry; t.right = next;
             f.nodes.push_back(t);
             next = RT_MAKE_REF(RT_REF_NODE, f.nodes.size() - 1);
+            for (int c = 0; c < 3; ++c) { acc.lo[c] = std::min(acc.lo[c], bounds[k].lo[c]); acc.hi[c] = std::max(acc.hi[c], bounds[k].hi[c]); }
         }
         tree_ref = next;
     }

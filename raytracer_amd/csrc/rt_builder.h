@@ -91,6 +91,7 @@ struct rt_builder {
     int build_bvh_node(std::vector<BNode>& tree, std::vector<int>& objects, const std::vector<double>& keys, size_t start,
                        size_t end, double t0, double t1);
     uint32_t emit(Flat& f, int h, int parent, uint32_t depth, uint32_t& need);
-    uint32_t emit_bvh(Flat& f, const ObjRec& o, int node, int parent, uint32_t depth, uint32_t& need);
+    uint32_t emit_bvh(Flat& f, const ObjRec& o, int parent, uint32_t depth, uint32_t& need);
+    uint32_t emit_replay(Flat& f, const ObjRec& o, int node, int parent, uint32_t depth, uint32_t& need);
     int compile(int world, void** blob, size_t* nbytes);
 };

@@ -74,46 +74,52 @@ RT_HD Ray rt_ray_to_level(const DScene& sc, const Ray& wray, int32_t inst) {
 
 // ---- primitive tests: return t only; the shade stage re-derives p / normal / uv from (ray, t) -------
 
-// AABB::hit (aabb.rs:35-75) on the node's f32 bounds widened to f64, same arithmetic as the reference -
+// AABB::hit (aabb.rs:35-75) on f32 bounds widened to f64, same arithmetic as the reference -
 // (bound - origin) * (1/d) per slab - arranged for fewer instructions:
 //   * the near / far bound of each axis is picked by the sign of 1/d instead of swapping t0 and t1 afterwards
 //     (the same two products, selected before instead of after);
 //   * the reference returns after any axis that empties the interval; the interval only ever shrinks, so one
-//     test after the third axis gives the same verdict, and the whole node is fetched up front.
-// NaN (a zero direction component against a coincident bound) leaves the interval unchanged exactly as the
-// reference's `if t0 > t_min` selects do.
+//     test after the third axis gives the same verdict;
+//   * the reference's `if t0 > t_min {t0} else {t_min}` ignores a NaN t0 (a zero direction component against a
+//     coincident bound); so does fmax, and t_min itself is never NaN. The far side is reduced the same way and
+//     joined with t_max by a select, because t_max (the closest hit so far) CAN be NaN - an axis-parallel ray
+//     in the plane of a rect (arrect.rs:32-40) - and the reference then accepts every box.
+// Returns whether the box is hit and the distance at which the ray enters it (>= t_min).
 struct RtSlab {
     V3 inv; // 1 / d (aabb.rs:36,49,62)
+    bool nx, ny, nz; // inv < 0 per axis (aabb.rs:39,52,65)
 };
 RT_HD RtSlab rt_slab_of(const Ray& r) {
     RtSlab s;
     s.inv = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    s.nx = s.inv.x < 0.0; s.ny = s.inv.y < 0.0; s.nz = s.inv.z < 0.0;
     return s;
 }
-RT_HD bool rt_aabb_hit(const RtNode& n, const Ray& r, const RtSlab& k, double t_min, double t_max) {
-    const bool nx = k.inv.x < 0.0, ny = k.inv.y < 0.0, nz = k.inv.z < 0.0;
-    const double t0x = ((double)(nx ? n.hi[0] : n.lo[0]) - r.o.x) * k.inv.x;
-    const double t1x = ((double)(nx ? n.lo[0] : n.hi[0]) - r.o.x) * k.inv.x;
-    const double t0y = ((double)(ny ? n.hi[1] : n.lo[1]) - r.o.y) * k.inv.y;
-    const double t1y = ((double)(ny ? n.lo[1] : n.hi[1]) - r.o.y) * k.inv.y;
-    const double t0z = ((double)(nz ? n.hi[2] : n.lo[2]) - r.o.z) * k.inv.z;
-    const double t1z = ((double)(nz ? n.lo[2] : n.hi[2]) - r.o.z) * k.inv.z;
-    t_min = t0x > t_min ? t0x : t_min;
-    t_max = t1x < t_max ? t1x : t_max;
-    t_min = t0y > t_min ? t0y : t_min;
-    t_max = t1y < t_max ? t1y : t_max;
-    t_min = t0z > t_min ? t0z : t_min;
-    t_max = t1z < t_max ? t1z : t_max;
-    return !(t_max <= t_min);
+RT_HD bool rt_aabb_hit(const float (&lo)[3], const float (&hi)[3], const Ray& r, const RtSlab& k, double t_min, double t_max,
+                       double& t_enter) {
+    const double t0x = ((double)(k.nx ? hi[0] : lo[0]) - r.o.x) * k.inv.x;
+    const double t1x = ((double)(k.nx ? lo[0] : hi[0]) - r.o.x) * k.inv.x;
+    const double t0y = ((double)(k.ny ? hi[1] : lo[1]) - r.o.y) * k.inv.y;
+    const double t1y = ((double)(k.ny ? lo[1] : hi[1]) - r.o.y) * k.inv.y;
+    const double t0z = ((double)(k.nz ? hi[2] : lo[2]) - r.o.z) * k.inv.z;
+    const double t1z = ((double)(k.nz ? lo[2] : hi[2]) - r.o.z) * k.inv.z;
+    const double t_near = fmax(fmax(fmax(t0x, t_min), t0y), t0z);
+    const double t_far = fmin(fmin(t1x, t1y), t1z);
+    t_max = t_far < t_max ? t_far : t_max;
+    t_enter = t_near;
+    return !(t_max <= t_near);
 }
-// One node record as two 16-byte loads (records are 32-byte aligned).
+// One node record as four 16-byte loads (records are 64-byte aligned).
 RT_HD RtNode rt_load_node(const RtNode* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint4 a = *(const uint4*)p, b = *((const uint4*)p + 1);
+    const uint4 a = *(const uint4*)p, b = *((const uint4*)p + 1), c = *((const uint4*)p + 2), d = *((const uint4*)p + 3);
     RtNode n;
-    n.lo[0] = __uint_as_float(a.x); n.lo[1] = __uint_as_float(a.y); n.lo[2] = __uint_as_float(a.z);
-    n.hi[0] = __uint_as_float(a.w); n.hi[1] = __uint_as_float(b.x); n.hi[2] = __uint_as_float(b.y);
-    n.left = b.z; n.right = b.w;
+    n.lo0[0] = __uint_as_float(a.x); n.lo0[1] = __uint_as_float(a.y); n.lo0[2] = __uint_as_float(a.z);
+    n.hi0[0] = __uint_as_float(a.w); n.hi0[1] = __uint_as_float(b.x); n.hi0[2] = __uint_as_float(b.y);
+    n.lo1[0] = __uint_as_float(b.z); n.lo1[1] = __uint_as_float(b.w); n.lo1[2] = __uint_as_float(c.x);
+    n.hi1[0] = __uint_as_float(c.y); n.hi1[1] = __uint_as_float(c.z); n.hi1[2] = __uint_as_float(c.w);
+    n.c0 = d.x; n.c1 = d.y;
+    n.pad[0] = 0u; n.pad[1] = 0u;
     return n;
 #else
     return *p;
@@ -339,16 +345,28 @@ struct RtTrav {
     uint32_t cur; // next reference to process; RT_REF_NONE = finished
 };
 
-// One box test: s.cur must be a node. BvhNode::hit (bvh.rs:112-122): box against the current closest distance,
-// then the left child, the right one kept for later. (Entering the child that lies nearer along the node's sort
-// axis first was measured: the extra selects cost ~25 % per step and the order itself helps one scene by 4 % and
-// hurts the random-sphere scenes, whose huge ground sphere is found early precisely by going left first.)
+// One node: s.cur must be a node. Both child boxes are tested against the current closest distance; the lane goes
+// on with the child the ray enters first and keeps the other for later.
+//
+// BvhNode::hit (bvh.rs:112-122) tests its own box, then the left child, then the right one with the tightened
+// t_max. Where every box really bounds its contents the closest hit does not depend on which boxes were tested,
+// when, or in which order, so such trees are stored with real boxes on both children and walked nearest first.
+// Where a box does not bound its contents (RotateY keeps its child's unrotated box, hittable.rs:115-143) what
+// the reference finds depends on exactly which boxes it tests and with which t_max, so those trees are encoded
+// to replay it: child 1 of a node carries the infinite box (entered at t_min, so never before child 0) and leads
+// to a one-child node holding the real right box, which is therefore tested only after the left subtree is done.
 template <class Stack>
 RT_HD void rt_trav_node_step(const DScene& sc, RtTrav& s, Stack& st, double t_min) {
     const RtNode n = rt_load_node(sc.nodes + RT_REF_INDEX(s.cur));
-    if (rt_aabb_hit(n, s.r, s.slab, t_min, s.best.t)) {
-        if (n.right != RT_REF_NONE) st.push(n.right);
-        s.cur = RT_REF_STRIP_AUX(n.left);
+    double e0, e1;
+    const bool h0 = rt_aabb_hit(n.lo0, n.hi0, s.r, s.slab, t_min, s.best.t, e0);
+    const bool h1 = rt_aabb_hit(n.lo1, n.hi1, s.r, s.slab, t_min, s.best.t, e1);
+    if (h0 && h1) {
+        const bool swap = e1 < e0;
+        st.push(swap ? n.c0 : n.c1);
+        s.cur = swap ? n.c1 : n.c0;
+    } else if (h0 || h1) {
+        s.cur = h0 ? n.c0 : n.c1;
     } else {
         s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop();
     }

@@ -5,12 +5,12 @@
 // table in the low 28), never a pointer, so the same bytes can be uploaded to any device address.
 //
 // Geometry is IEEE f64 like the reference (raytracer/src/vec3.rs:5-9); only BVH node bounds are
-// stored as f32, rounded outward so that the f32 box always contains the reference's f64 box.
+// stored as f32, rounded outward so that the f32 box always contains the f64 box it stands for.
 #pragma once
 #include <stdint.h>
 
 #define RT_BLOB_MAGIC 0x31425452u /* "RTB1" little endian */
-#define RT_BLOB_VERSION 6u
+#define RT_BLOB_VERSION 7u
 
 // ---- tagged references -------------------------------------------------------------------------
 enum RtRefType : uint32_t {
@@ -25,8 +25,7 @@ enum RtRefType : uint32_t {
     RT_REF_LIST = 8,     // HittableList: index of its first entry in the NONE-terminated entry array
     RT_REF_POP = 9       // traversal-internal marker: leave instance `index`
 };
-// layout: type[31:28] | aux[27:26] | index[25:0]. aux is used in one place only: in a node's `left` it holds
-// 1 + the axis the node's children were sorted on (bvh.rs:22-27), 0 = unknown.
+// layout: type[31:28] | aux[27:26] (unused, zero) | index[25:0]
 #define RT_REF_SHIFT 28u
 #define RT_REF_INDEX_MASK 0x03FFFFFFu
 #define RT_REF_AUX_SHIFT 26u
@@ -41,15 +40,16 @@ enum RtRefType : uint32_t {
 #define RT_STACK_CAP 40  /* per-lane traversal stack entries (LDS) */
 
 // ---- records -------------------------------------------------------------------------------------
-// 32-byte BVH node, nodes of one tree stored in depth-first pre-order (a node's left subtree follows
-// it immediately). `left`/`right` are refs: another node, or the object the reference would store
-// in that Arc. A span-1 node (bvh.rs:33-35, same object on both sides) carries right = NONE.
-// The aux bits of `left` record the sort axis, so a traversal may enter the nearer child first.
+// 64-byte BVH node: the boxes of BOTH children and their refs, so that one fetch decides both descents and the
+// nearer child can be entered first. A child ref is another node or the object the reference would store in that
+// Arc (bvh.rs:8-12). An absent child has ref NONE and the empty box (lo = +inf, hi = -inf), which no ray hits; a
+// child that must be entered without a box test (an object directly under a reference-order node, whose hit() has
+// no box of its own) has the infinite box. Nodes of one tree are stored in depth-first pre-order.
 struct RtNode {
-    float lo[3];
-    float hi[3];
-    uint32_t left;
-    uint32_t right;
+    float lo0[3], hi0[3]; // child 0
+    float lo1[3], hi1[3]; // child 1
+    uint32_t c0, c1;
+    uint32_t pad[2];
 };
 
 // Common per-primitive bookkeeping, one per geometry record (same index).
@@ -121,7 +121,8 @@ struct RtBlobHeader {
     RtSection nodes, spheres, sphere_meta, mspheres, msphere_meta, rects, rect_meta, boxes, box_meta,
         media, insts, list_entries, materials, textures, perlin_vec, perlin_perm, texels;
 };
-#define RT_BLOB_FLAG_BOOK_BBOX 1u /* RotateY stores its rotated box (book behaviour) instead of the child's */
+#define RT_BLOB_FLAG_BOOK_BBOX 1u      /* RotateY stores its rotated box (book behaviour) instead of the child's */
+#define RT_BLOB_FLAG_REFERENCE_TREE 2u /* every BvhNode keeps the reference's topology (random-axis median split) */
 
 // ---- render-time records -------------------------------------------------------------------------
 // Camera in the derived form the reference's Camera struct holds (camera.rs:7-18).

@@ -93,14 +93,32 @@ def header(blob):
                 max_chain=max_chain, flags=flags, n_objects=n_objects, sections={n: tuple(map(int, s)) for n, s in zip(names, secs)})
 
 
+NODE = np.dtype([("lo0", "<f4", 3), ("hi0", "<f4", 3), ("lo1", "<f4", 3), ("hi1", "<f4", 3), ("c0", "<u4"), ("c1", "<u4"), ("pad", "<u4", 2)])
+REFERENCE_TREE = 2
+
+
+def nodes_of(blob, h):
+    assert NODE.itemsize == 64
+    off, cnt = h["sections"]["nodes"]
+    return np.frombuffer(blob, dtype=NODE, count=cnt, offset=off)
+
+
+def is_empty(lo, hi):
+    return np.all(np.isposinf(lo)) and np.all(np.isneginf(hi))
+
+
+def is_infinite(lo, hi):
+    return np.all(np.isneginf(lo)) and np.all(np.isposinf(hi))
+
+
 def test_blob_layout_of_the_book2_final_scene():
     _, info, blob, _ = util.build_scene("final_scene")
     h = header(blob)
     assert h["magic"] == 0x31425452 and h["total"] == len(blob) and len(blob) % 256 == 0
     s = h["sections"]
-    # BvhNode counts of the reference's recursion (bvh.rs:33-50): 400 boxes -> 511 nodes, 1000 spheres -> 1023
-    # + 2 bounding nodes the compiler adds above the two trees (one in front of the instanced BVH, one joining both)
-    assert s["nodes"][1] == 511 + 1023 + 2
+    # one node per internal split, one object per leaf: 400 boxes -> 399 nodes, 1000 spheres -> 999,
+    # + one bounding node per tree of the world list
+    assert s["nodes"][1] == 399 + 999 + 2
     assert s["boxes"][1] == 400 and s["mspheres"][1] == 1 and s["rects"][1] == 1
     assert s["spheres"][1] == 1000 + 5 + 2            # + the two medium boundaries (one is the shared r=70 sphere again)
     assert s["media"][1] == 2 == h["n_media"] and s["insts"][1] == 2 and h["max_chain"] == 2
@@ -116,63 +134,85 @@ def test_blob_layout_of_the_book2_final_scene():
     flat = entries[flat_first:flat_first + 10]
     assert (h["world_flat"] >> 28) == 8 and np.count_nonzero(flat[:9]) == 9 and flat[9] == 0
     assert set(flat[:9].tolist()) <= set(entries[world_first:world_first + 11].tolist())
-    # the 2 trees under bounding nodes: top = {left: BVH of boxes (node 0), right: {left: the Translate instance}}
-    nodes = np.frombuffer(blob, dtype=np.dtype([("lo", "<f4", 3), ("hi", "<f4", 3), ("left", "<u4"), ("right", "<u4")]),
-                          count=s["nodes"][1], offset=s["nodes"][0])
+    # the 2 trees under bounding nodes: top = {the BVH of boxes (node 0), next = {the Translate instance, nothing}}
+    nodes = nodes_of(blob, h)
     assert (h["world_tree"] >> 28) == 1
     top = nodes[h["world_tree"] & 0x03FFFFFF]
-    assert top["left"] == (1 << 28) | 0 and (top["right"] >> 28) == 1      # added nodes carry no sort axis
-    wrap = nodes[top["right"] & 0x03FFFFFF]
-    assert (wrap["left"] >> 28) == 7 and wrap["right"] == 0
+    assert top["c0"] == (1 << 28) | 0 and (top["c1"] >> 28) == 1
+    wrap = nodes[top["c1"] & 0x03FFFFFF]
+    assert (wrap["c0"] >> 28) == 7 and wrap["c1"] == 0 and is_empty(wrap["lo1"], wrap["hi1"])
     # the instanced cluster: spheres r=10 with centres in [0,165)^3, rotated 15 degrees about y, moved by (-100,270,395)
-    assert np.all(wrap["lo"] < [-100, 265, 345]) and np.all(wrap["hi"] > [60, 430, 540])
-    assert np.all(wrap["lo"] > [-170, 250, 330]) and np.all(wrap["hi"] < [130, 450, 620])
-    assert np.all(top["lo"] <= np.minimum(wrap["lo"], nodes[0]["lo"])) and np.all(top["hi"] >= np.maximum(wrap["hi"], nodes[0]["hi"]))
+    assert np.all(wrap["lo0"] < [-100, 265, 345]) and np.all(wrap["hi0"] > [60, 430, 540])
+    assert np.all(wrap["lo0"] > [-170, 250, 330]) and np.all(wrap["hi0"] < [130, 450, 620])
+    assert np.array_equal(top["lo1"], wrap["lo0"]) and np.array_equal(top["hi1"], wrap["hi0"])
+    # the 400 ground boxes: x, z in [-1000, 1000], tops below 101
+    assert np.all(top["lo0"] <= [-1000, 0, -1000]) and np.all(top["hi0"] >= [1000, 1, 1000]) and top["hi0"][1] < 102
 
 
-def test_cornell_has_seven_nodes_and_f32_bounds_contain_the_f64_boxes():
+def test_cornell_replays_the_reference_order():
     b, info, blob, _ = util.build_scene("cornell_box")
     h = header(blob)
-    assert h["sections"]["nodes"][1] == 7 and h["world_tree"] == (1 << 28) | 0 and h["world_flat"] == 0
-    # its RotateY instances keep unrotated boxes: no node may offer a traversal order other than the reference's
-    cn = np.frombuffer(blob, dtype="<u4", count=7 * 8, offset=h["sections"]["nodes"][0]).reshape(7, 8)
-    assert np.all((cn[:, 6] >> 26) & 3 == 0)
+    # 8 objects -> 7 BvhNodes (bvh.rs:33-50); each node one record, + one record in front of the root and of every
+    # right child that is a node (their own boxes, tested when the reference tests them) + the world's bounding node
+    nodes = nodes_of(blob, h)
+    assert len(nodes) == 7 + 1 + 3 + 1 and h["world_flat"] == 0 and (h["world_tree"] >> 28) == 1
     assert h["sections"]["rects"][1] == 6 and h["sections"]["boxes"][1] == 2
-    # a BVH over known spheres: every node's f32 box must contain the exact f64 union of its subtree
+    # its RotateY instances keep unrotated boxes: no record below the world's may leave the order to the ray
+    # (child 1 is absent, or is entered at t_min like nothing else can be)
+    for i, n in enumerate(nodes[:-1]):
+        assert is_empty(n["lo1"], n["hi1"]) if n["c1"] == 0 else is_infinite(n["lo1"], n["hi1"]), i
+    top = nodes[h["world_tree"] & 0x03FFFFFF]
+    assert top["c0"] == (1 << 28) | 0 and top["c1"] == 0
+    root_gate = nodes[0]
+    assert root_gate["c0"] == (1 << 28) | 1 and root_gate["c1"] == 0
+    assert np.all(root_gate["lo0"] <= [0, 0, 0]) and np.all(root_gate["hi0"] >= [555, 555, 555]) and np.all(root_gate["hi0"] < 556)
+
+
+@pytest.mark.parametrize("flags", [0, REFERENCE_TREE])
+def test_tree_boxes_contain_and_hug_their_subtrees(flags):
     rng = np.random.default_rng(3)
-    b = api.Builder()
+    b = api.Builder(flags=flags)
     m = b.lambertian_color(1, 1, 1)
     c = rng.uniform(-1000, 1000, (257, 3)) + rng.uniform(0, 1e-3, (257, 3))
     r = rng.uniform(0.1, 3.0, 257)
     lst = b.list([b.sphere(tuple(ci), float(ri), m) for ci, ri in zip(c, r)])
     blob = b.compile(b.list([b.bvh(lst, 0, 1)]))
     h = header(blob)
-    off, cnt = h["sections"]["nodes"]
-    nodes = np.frombuffer(blob, dtype=np.dtype([("lo", "<f4", 3), ("hi", "<f4", 3), ("left", "<u4"), ("right", "<u4")]), count=cnt, offset=off)
+    nodes = nodes_of(blob, h)
     so, sn = h["sections"]["spheres"]
     sph = np.frombuffer(blob, dtype="<f8", count=sn * 4, offset=so).reshape(sn, 4)
-    assert cnt == 2 * 256 - 1 + 0 or cnt >= 257 // 2    # one node per internal split plus span-1/2 leaves
+    if flags == 0:
+        assert len(nodes) == 256 + 1     # one object per leaf; + the world's bounding node
+    seen = []
 
     def bounds(ref):
         ty, idx = ref >> 28, ref & 0x03FFFFFF
+        assert (ref >> 26) & 3 == 0
         if ty == 2:
+            seen.append(idx)
             return sph[idx, :3] - sph[idx, 3], sph[idx, :3] + sph[idx, 3]
         assert ty == 1
         n = nodes[idx]
-        assert (int(n["left"]) >> 26) & 3 == 0                                  # no sort axis published
-        lo, hi = bounds(int(n["left"]) & ~(3 << 26))
-        if n["right"]:
-            lo2, hi2 = bounds(int(n["right"]))
-            lo, hi = np.minimum(lo, lo2), np.maximum(hi, hi2)
-        assert np.all(n["lo"].astype(np.float64) <= lo) and np.all(n["hi"].astype(np.float64) >= hi)
-        # and tight: within one f32 ulp
-        assert np.all(lo - n["lo"].astype(np.float64) <= np.spacing(np.abs(n["lo"])).astype(np.float64))
-        return lo, hi
-    bounds(1 << 28)
-    # depth-first pre-order: a node's left child, when it is a node, is the next record
-    for i, n in enumerate(nodes):
-        if n["left"] >> 28 == 1:
-            assert (n["left"] & 0x03FFFFFF) == i + 1
+        out = None
+        for cref, lo32, hi32 in ((int(n["c0"]), n["lo0"], n["hi0"]), (int(n["c1"]), n["lo1"], n["hi1"])):
+            if cref == 0:
+                assert is_empty(lo32, hi32)
+                continue
+            lo, hi = bounds(cref)
+            assert np.all(lo32.astype(np.float64) <= lo) and np.all(hi32.astype(np.float64) >= hi)
+            # and tight: within one f32 ulp
+            assert np.all(lo - lo32.astype(np.float64) <= np.spacing(np.abs(lo32)).astype(np.float64))
+            assert np.all(hi32.astype(np.float64) - hi <= np.spacing(np.abs(hi32)).astype(np.float64))
+            out = (lo, hi) if out is None else (np.minimum(out[0], lo), np.maximum(out[1], hi))
+        return out
+    top = nodes[h["world_tree"] & 0x03FFFFFF]       # the world's bounding node keeps a margin (frame changes round)
+    lo, hi = bounds(int(top["c0"]))
+    assert top["c1"] == 0 and np.all(top["lo0"] < lo) and np.all(top["hi0"] > hi) and np.all(top["hi0"] - hi < 0.01)
+    assert sorted(seen) == list(range(257))          # every sphere under exactly one leaf
+    # depth-first pre-order: child 0, when it is a node, is the next record
+    for i, n in enumerate(nodes[:-1]):
+        if n["c0"] >> 28 == 1:
+            assert (n["c0"] & 0x03FFFFFF) == i + 1
 
 
 def test_description_log_replays_to_the_same_scene_twice():
@@ -184,7 +224,7 @@ def test_description_log_replays_to_the_same_scene_twice():
 def test_one_million_sphere_scene_compiles():
     b, info, blob, _ = util.build_scene("spheres_grid", n=1_000_000)
     h = header(blob)
-    # 1,000,001 objects -> the reference's recursion yields 2^20 - 1 nodes (depth 20)
-    assert h["sections"]["nodes"][1] == 1_048_575
+    # 1,000,001 objects, one per leaf -> 1,000,000 nodes, + the world's bounding node
+    assert h["sections"]["nodes"][1] == 1_000_001
     assert h["sections"]["spheres"][1] + h["sections"]["mspheres"][1] == 1_000_001
     assert h["stack_need"] <= 40 and info.width == 3840 and info.height == 2160

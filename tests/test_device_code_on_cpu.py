@@ -28,7 +28,7 @@ def test_first_hit_matches_oracle(name):
     rep = util.first_hit_report(got, want)
     assert rep["prim_match"] == 1.0, rep
     assert rep["t_bit_equal"] == 1.0, rep                          # same libm on both sides here: exact
-    assert rep["ties"] < 0.01
+    assert rep["ties"] < 0.02
     same = got["prim_id"] == want["prim_id"]
     for f in ("px", "py", "pz", "nx", "ny", "nz"):
         assert np.array_equal(got[f][same].view(np.uint64), want[f][same].view(np.uint64)), f     # bit compare: NaN == NaN
