@@ -667,6 +667,28 @@ RT_HD bool rt_material_reads_uv(const DScene& sc, const RtMaterial& m) {
 }
 
 // ---- materials -----------------------------------------------------------------------------------------
+RT_HD uint32_t rt_bucket_of(uint32_t mat_type, uint32_t tex_type) {
+    const uint32_t tex = tex_type == RT_TEX_SOLID ? 0u : 1u;
+    switch (mat_type) {
+    case RT_MAT_LAMBERTIAN: return RT_BUCKET_LAMBERTIAN_SOLID + tex;
+    case RT_MAT_METAL: return RT_BUCKET_METAL;
+    case RT_MAT_DIELECTRIC: return RT_BUCKET_DIELECTRIC;
+    case RT_MAT_DIFFUSE_LIGHT: return RT_BUCKET_LIGHT_SOLID + tex;
+    default: return RT_BUCKET_ISOTROPIC_SOLID + tex;
+    }
+}
+constexpr uint32_t rt_bucket_material(uint32_t bucket) {
+    return bucket <= RT_BUCKET_LAMBERTIAN_TEX ? RT_MAT_LAMBERTIAN : bucket == RT_BUCKET_METAL ? RT_MAT_METAL
+         : bucket == RT_BUCKET_DIELECTRIC ? RT_MAT_DIELECTRIC : bucket <= RT_BUCKET_LIGHT_TEX ? RT_MAT_DIFFUSE_LIGHT : RT_MAT_ISOTROPIC;
+}
+constexpr bool rt_bucket_solid(uint32_t bucket) {
+    return bucket == RT_BUCKET_LAMBERTIAN_SOLID || bucket == RT_BUCKET_LIGHT_SOLID || bucket == RT_BUCKET_ISOTROPIC_SOLID;
+}
+// SolidColor::value (texture.rs:23-27) when the caller knows the texture is one
+RT_HD V3 rt_tex_solid_value(const DScene& sc, uint32_t tex) {
+    const RtTexture t = sc.textures[tex];
+    return v3(t.p[0], t.p[1], t.p[2]);
+}
 struct ShadeOut {
     V3 emitted;      // Material::emitted (material.rs:19-21, 201-203)
     V3 attenuation;
@@ -681,8 +703,8 @@ RT_HD double rt_reflectance(double cosine, double ref_idx) {
 }
 // emitted + scatter for the material of `rec`, the two calls ray_color makes at main.rs:62-66.
 // MAT = the material type when the caller knows it at compile time (the per-material shade kernels), which prunes
-// the other four bodies; RT_MAT_COUNT = decide from m.type at run time.
-template <uint32_t MAT>
+// the other four bodies; RT_MAT_COUNT = decide from m.type at run time. SOLID = the caller knows the texture is a SolidColor.
+template <uint32_t MAT, bool SOLID = false>
 RT_HD ShadeOut rt_shade_as(const DScene& sc, const RtMaterial& m, const Ray& r_in, const HitRec& rec, const Sampler& smp) {
     ShadeOut o;
     o.emitted = v3(0.0, 0.0, 0.0);
@@ -696,7 +718,7 @@ RT_HD ShadeOut rt_shade_as(const DScene& sc, const RtMaterial& m, const Ray& r_i
         V3 scatter_direction = rec.normal + rt_random_unit_vector(smp);
         if (v3_near_zero(scatter_direction)) scatter_direction = rec.normal;
         o.scattered.o = rec.p; o.scattered.d = scatter_direction; o.scattered.tm = r_in.tm;
-        o.attenuation = rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+        o.attenuation = SOLID ? rt_tex_solid_value(sc, m.tex) : rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p);
         o.did_scatter = true;
         break;
     }
@@ -728,12 +750,12 @@ RT_HD ShadeOut rt_shade_as(const DScene& sc, const RtMaterial& m, const Ray& r_i
         break;
     }
     case RT_MAT_DIFFUSE_LIGHT: { // material.rs:191-204: both faces emit
-        o.emitted = rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p) * m.p[0];
+        o.emitted = (SOLID ? rt_tex_solid_value(sc, m.tex) : rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p)) * m.p[0];
         break;
     }
     case RT_MAT_ISOTROPIC: { // material.rs:219-231: direction is not normalised
         o.scattered.o = rec.p; o.scattered.d = rt_random_in_unit_sphere(smp); o.scattered.tm = r_in.tm;
-        o.attenuation = rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+        o.attenuation = SOLID ? rt_tex_solid_value(sc, m.tex) : rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p);
         o.did_scatter = true;
         break;
     }

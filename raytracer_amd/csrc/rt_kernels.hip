@@ -31,7 +31,8 @@
 #define RT_BLOCK 256
 #define RT_TREE_CHUNK 1024u /* queue indices a persistent wave reserves per atomic */
 #define RT_BIN_PER_THREAD 8  /* rays per thread in k_bin */
-#define RT_COUNTER_STRIDE 8u /* per iteration: [0] live paths entering it, [1+m] hits on material type m */
+#define RT_COUNTER_STRIDE 16u /* per iteration: [0] live paths entering it, [1+b] hits queued for shading bucket b, [RT_COUNTER_HEAD] */
+#define RT_COUNTER_HEAD 9u    /* queue head of the persistent tree kernel */
 
 // ---- device structures ------------------------------------------------------------------------------------
 // Path state, one record per path, each record one 64-byte line: once the live queue has been compacted the slots a
@@ -51,8 +52,9 @@ struct PassInfo {
 };
 struct QueueSet {
     uint32_t* live[2];          // slot ids entering iteration it: live[it & 1]
-    uint32_t* bucket[RT_MAT_COUNT];
-    uint32_t* counters;         // (max_depth + 1) * RT_COUNTER_STRIDE
+    uint32_t* bucket;           // RT_BUCKET_COUNT queues of bucket_cap entries each, one per shading bucket
+    size_t bucket_cap;
+    uint32_t* counters;         // (max_depth + 2) * RT_COUNTER_STRIDE
     uint32_t* error_flag;       // bit 0: traversal stack overflow
 };
 
@@ -120,6 +122,44 @@ __device__ inline void block_append(const bool (&take)[R], const uint32_t (&slot
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if (take[r]) q[base + rank[r]] = slot[r];
+}
+
+// R items per thread, each for one of Q queues (which[r] >= Q: none): one atomic per queue per call, two barriers.
+// Queue q starts at qbase + q * qcap and counts in counters[q]. `lds` = Q * RT_BLOCK/64 words. Every thread of the
+// block must call it; a barrier must separate two calls.
+template <int R, int Q>
+__device__ inline void block_append_multi(const uint32_t (&which)[R], const uint32_t (&slot)[R], uint32_t* qbase, size_t qcap,
+                                          uint32_t* counters, uint32_t* lds) {
+    constexpr uint32_t W = RT_BLOCK / 64u;
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t rank[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) rank[r] = 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < (uint32_t)Q; ++q) {
+        uint32_t mine = 0u; // the wave's count for queue q so far (identical in every lane)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool take = which[r] == q;
+            const unsigned long long mask = __ballot(take);
+            if (take) rank[r] = mine + (uint32_t)__popcll(mask & below);
+            mine += (uint32_t)__popcll(mask);
+        }
+        if (lane == 0u) lds[q * W + wave] = mine;
+    }
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)Q) {
+        const uint32_t q = threadIdx.x;
+        uint32_t total = 0u;
+        for (uint32_t w = 0; w < W; ++w) { const uint32_t c = lds[q * W + w]; lds[q * W + w] = total; total += c; }
+        const uint32_t base = total ? atomicAdd(counters + q, total) : 0u;
+        for (uint32_t w = 0; w < W; ++w) lds[q * W + w] += base;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (which[r] < (uint32_t)Q) qbase[(size_t)which[r] * qcap + lds[which[r] * W + wave] + rank[r]] = slot[r];
 }
 
 __device__ inline Ray load_ray(const PathBufs& pb, uint32_t slot) {
@@ -217,7 +257,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_extend_tree(DScene sc, PassInfo pi
     const uint32_t* live = it == 0u ? nullptr : qs.live[it & 1u];
     uint32_t* ctr = qs.counters + it * RT_COUNTER_STRIDE;
     const uint32_t n = ctr[0];
-    uint32_t* head = ctr + 6u;
+    uint32_t* head = ctr + RT_COUNTER_HEAD;
     LdsStack st;
     st.base = lds_stack + threadIdx.x;
     st.cap = stack_cap;
@@ -294,19 +334,19 @@ __global__ void __launch_bounds__(RT_BLOCK) k_extend_tree(DScene sc, PassInfo pi
 }
 
 __global__ void __launch_bounds__(RT_BLOCK) k_bin(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it) {
-    __shared__ uint32_t scratch[RT_BLOCK / 64 + 1];
+    __shared__ uint32_t lds[RT_BUCKET_COUNT * (RT_BLOCK / 64)];
     const uint32_t* live = it == 0u ? nullptr : qs.live[it & 1u];
     uint32_t* ctr = qs.counters + it * RT_COUNTER_STRIDE;
     const uint32_t n = ctr[0];
     const uint32_t per_block = RT_BLOCK * RT_BIN_PER_THREAD;
-    // whole blocks iterate together: block_append synchronises the block
+    // whole blocks iterate together: the append synchronises the block
     for (uint32_t base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
-        uint32_t slot[RT_BIN_PER_THREAD], mat_type[RT_BIN_PER_THREAD];
+        uint32_t slot[RT_BIN_PER_THREAD], bucket[RT_BIN_PER_THREAD];
 #pragma unroll
         for (int r = 0; r < RT_BIN_PER_THREAD; ++r) {
             const uint32_t i = base + (uint32_t)r * RT_BLOCK + threadIdx.x;
             slot[r] = 0u;
-            mat_type[r] = 0xFFFFFFFFu;
+            bucket[r] = 0xFFFFFFFFu;
             if (i < n) {
                 slot[r] = live ? live[i] : i;
                 const RtHitLite h = pb.hit[slot[r]];
@@ -324,26 +364,25 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bin(DScene sc, PassInfo pi, PathBu
                     else if (ty == RT_REF_RECT) m = sc.rect_meta[idx].material;
                     else if (ty == RT_REF_BOX) m = sc.box_meta[idx].material;
                     else m = sc.media[idx].material;
-                    mat_type[r] = sc.materials[m].type;
+                    const uint32_t mt = sc.materials[m].type;
+                    const bool textured = mt == RT_MAT_LAMBERTIAN || mt == RT_MAT_DIFFUSE_LIGHT || mt == RT_MAT_ISOTROPIC;
+                    bucket[r] = rt_bucket_of(mt, textured ? sc.textures[sc.materials[m].tex].type : (uint32_t)RT_TEX_SOLID);
                 }
             }
         }
-#pragma unroll 1
-        for (uint32_t m = 0; m < RT_MAT_COUNT; ++m) {
-            bool take[RT_BIN_PER_THREAD];
-#pragma unroll
-            for (int r = 0; r < RT_BIN_PER_THREAD; ++r) take[r] = mat_type[r] == m;
-            block_append<RT_BIN_PER_THREAD>(take, slot, qs.bucket[m], ctr + 1u + m, scratch);
-        }
+        block_append_multi<RT_BIN_PER_THREAD, RT_BUCKET_COUNT>(bucket, slot, qs.bucket, qs.bucket_cap, ctr + 1u, lds);
+        __syncthreads();
     }
 }
 
 // emitted + scatter (main.rs:60-70) for every path of iteration `it` that hit a material of type MAT.
-template <uint32_t MAT>
+template <uint32_t BUCKET>
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it) {
+    constexpr uint32_t MAT = rt_bucket_material(BUCKET);
+    constexpr bool SOLID = rt_bucket_solid(BUCKET);
     __shared__ uint32_t scratch[RT_BLOCK / 64 + 1];
-    const uint32_t* bucket = qs.bucket[MAT];
-    const uint32_t n = qs.counters[it * RT_COUNTER_STRIDE + 1u + MAT];
+    const uint32_t* bucket = qs.bucket + (size_t)BUCKET * qs.bucket_cap;
+    const uint32_t n = qs.counters[it * RT_COUNTER_STRIDE + 1u + BUCKET];
     uint32_t* next = qs.live[(it + 1u) & 1u];
     uint32_t* next_counter = qs.counters + (it + 1u) * RT_COUNTER_STRIDE;
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
@@ -363,10 +402,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
             else if (ty == RT_REF_BOX) mi = sc.box_meta[idx].material;
             else mi = sc.media[idx].material;
             const RtMaterial m = sc.materials[mi];
-            const bool uv = (MAT == RT_MAT_METAL || MAT == RT_MAT_DIELECTRIC) ? false : rt_material_reads_uv(sc, m);
+            const bool uv = (SOLID || MAT == RT_MAT_METAL || MAT == RT_MAT_DIELECTRIC) ? false : rt_material_reads_uv(sc, m);
             const HitRec rec = rt_reconstruct(sc, r, h, uv);
             const Sampler smp = slot_sampler(pi, slot, it);
-            const ShadeOut o = rt_shade_as<MAT>(sc, m, r, rec, smp);
+            const ShadeOut o = rt_shade_as<MAT, SOLID>(sc, m, r, rec, smp);
             if (MAT == RT_MAT_DIFFUSE_LIGHT) { // the only material whose emitted() is not black
                 PathAcc* acc = pb.acc + slot;
                 acc->rr += acc->tr * o.emitted.x;
@@ -462,6 +501,7 @@ struct rt_scene {
     RtBlobHeader hdr;
     DScene view;
     bool has_flat = true, has_tree = true; // whether the world holds plain primitives / BVHs at all
+    uint32_t bucket_mask = 0;              // shading buckets some material of the scene falls into
 };
 
 struct rt_context {
@@ -473,7 +513,7 @@ struct rt_context {
     size_t cap_paths = 0;
     double* f64pool = nullptr; // cap_paths PathRay records, then cap_paths PathAcc records
     RtHitLite* hit = nullptr;
-    uint32_t* u32pool = nullptr; // 2 live queues + 5 buckets, cap_paths each
+    uint32_t* u32pool = nullptr; // 2 live queues + RT_BUCKET_COUNT bucket queues, cap_paths each
     uint32_t* counters = nullptr;
     size_t cap_counters = 0;
     uint32_t* error_flag = nullptr;
@@ -553,7 +593,7 @@ int ensure_paths(rt_context* ctx, size_t paths, uint32_t max_depth) {
         ctx->f64pool = nullptr; ctx->hit = nullptr; ctx->u32pool = nullptr; ctx->cap_paths = 0;
         RT_HIP(hipMalloc((void**)&ctx->f64pool, paths * (sizeof(PathRay) + sizeof(PathAcc))), "hipMalloc path state");
         RT_HIP(hipMalloc((void**)&ctx->hit, paths * sizeof(RtHitLite)), "hipMalloc hit records");
-        RT_HIP(hipMalloc((void**)&ctx->u32pool, paths * 7 * sizeof(uint32_t)), "hipMalloc queues");
+        RT_HIP(hipMalloc((void**)&ctx->u32pool, paths * (2 + RT_BUCKET_COUNT) * sizeof(uint32_t)), "hipMalloc queues");
         ctx->cap_paths = paths;
     }
     const size_t need = (size_t)(max_depth + 2) * RT_COUNTER_STRIDE;
@@ -627,12 +667,13 @@ struct EventTimer { // brackets launches with events when profiling; sums are re
     }
 };
 
-template <uint32_t MAT>
+template <uint32_t BUCKET>
 void launch_shade(rt_context* ctx, const rt_scene* sc, const PassInfo& pi, const PathBufs& pb, const QueueSet& qs, uint32_t it,
                   uint32_t grid, EventTimer& tm) {
+    if (!(sc->bucket_mask >> BUCKET & 1u)) return; // no material of the scene is shaded by this kernel
     size_t a = tm.begin();
-    hipLaunchKernelGGL(k_shade<MAT>, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, sc->view, pi, pb, qs, it);
-    tm.end(a, 2 + (int)MAT);
+    hipLaunchKernelGGL(k_shade<BUCKET>, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, sc->view, pi, pb, qs, it);
+    tm.end(a, 2 + (int)rt_bucket_material(BUCKET));
 }
 
 } // namespace
@@ -701,6 +742,21 @@ static int upload_common(rt_context* ctx, const void* src, size_t nbytes, bool s
     make_view(s);
     s->has_flat = s->hdr.world_flat != RT_REF_NONE;
     s->has_tree = s->hdr.world_tree != RT_REF_NONE;
+    {
+        std::vector<RtMaterial> mats(s->hdr.materials.count);
+        std::vector<RtTexture> texs(s->hdr.textures.count);
+        const uint8_t* b = (const uint8_t*)src;
+        const hipMemcpyKind kind = src_on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost;
+        if (!mats.empty()) e = hipMemcpy(mats.data(), b + s->hdr.materials.offset, mats.size() * sizeof(RtMaterial), kind);
+        if (e == hipSuccess && !texs.empty()) e = hipMemcpy(texs.data(), b + s->hdr.textures.offset, texs.size() * sizeof(RtTexture), kind);
+        if (e != hipSuccess) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_NO_DEVICE, "read material table", e); }
+        for (const RtMaterial& m : mats) {
+            if (m.type >= RT_MAT_COUNT) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_INVALID, "blob: unknown material type"); }
+            const bool textured = m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_DIFFUSE_LIGHT || m.type == RT_MAT_ISOTROPIC;
+            if (textured && m.tex >= texs.size()) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_INVALID, "blob: texture index out of range"); }
+            s->bucket_mask |= 1u << rt_bucket_of(m.type, textured ? texs[m.tex].type : (uint32_t)RT_TEX_SOLID);
+        }
+    }
     *out = s;
     return RT_OK;
 }
@@ -803,7 +859,8 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
     QueueSet qs;
     qs.live[0] = ctx->u32pool;
     qs.live[1] = ctx->u32pool + ctx->cap_paths;
-    for (int m = 0; m < RT_MAT_COUNT; ++m) qs.bucket[m] = ctx->u32pool + (size_t)(2 + m) * ctx->cap_paths;
+    qs.bucket = ctx->u32pool + 2 * ctx->cap_paths;
+    qs.bucket_cap = ctx->cap_paths;
     qs.counters = ctx->counters;
     qs.error_flag = ctx->error_flag;
 
@@ -856,11 +913,14 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
             a = tm.begin();
             hipLaunchKernelGGL(k_bin, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);
             tm.end(a, 9);
-            launch_shade<RT_MAT_LAMBERTIAN>(ctx, &local, pi, pb, qs, it, g_sh, tm);
-            launch_shade<RT_MAT_METAL>(ctx, &local, pi, pb, qs, it, g_sh, tm);
-            launch_shade<RT_MAT_DIELECTRIC>(ctx, &local, pi, pb, qs, it, g_sh, tm);
-            launch_shade<RT_MAT_DIFFUSE_LIGHT>(ctx, &local, pi, pb, qs, it, g_sh, tm);
-            launch_shade<RT_MAT_ISOTROPIC>(ctx, &local, pi, pb, qs, it, g_sh, tm);
+            launch_shade<RT_BUCKET_LAMBERTIAN_SOLID>(ctx, &local, pi, pb, qs, it, g_sh, tm);
+            launch_shade<RT_BUCKET_LAMBERTIAN_TEX>(ctx, &local, pi, pb, qs, it, g_sh, tm);
+            launch_shade<RT_BUCKET_METAL>(ctx, &local, pi, pb, qs, it, g_sh, tm);
+            launch_shade<RT_BUCKET_DIELECTRIC>(ctx, &local, pi, pb, qs, it, g_sh, tm);
+            launch_shade<RT_BUCKET_LIGHT_SOLID>(ctx, &local, pi, pb, qs, it, g_sh, tm);
+            launch_shade<RT_BUCKET_LIGHT_TEX>(ctx, &local, pi, pb, qs, it, g_sh, tm);
+            launch_shade<RT_BUCKET_ISOTROPIC_SOLID>(ctx, &local, pi, pb, qs, it, g_sh, tm);
+            launch_shade<RT_BUCKET_ISOTROPIC_TEX>(ctx, &local, pi, pb, qs, it, g_sh, tm);
         }
         a = tm.begin();
         hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx, n_local, 8)), dim3(RT_BLOCK), 0, ctx->stream, pi, pb, d_rgb_sum);

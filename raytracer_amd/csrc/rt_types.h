@@ -87,6 +87,13 @@ enum RtMaterialType : uint32_t {
     RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2, RT_MAT_DIFFUSE_LIGHT = 3,
     RT_MAT_ISOTROPIC = 4, RT_MAT_COUNT = 5
 };
+// Shading work is queued by what it has to run: material type, and whether the material's texture is a plain colour
+// (one table read) or anything else (Perlin noise, image, checker: an order of magnitude more code and registers).
+enum RtBucket : uint32_t {
+    RT_BUCKET_LAMBERTIAN_SOLID = 0, RT_BUCKET_LAMBERTIAN_TEX = 1, RT_BUCKET_METAL = 2, RT_BUCKET_DIELECTRIC = 3,
+    RT_BUCKET_LIGHT_SOLID = 4, RT_BUCKET_LIGHT_TEX = 5, RT_BUCKET_ISOTROPIC_SOLID = 6, RT_BUCKET_ISOTROPIC_TEX = 7,
+    RT_BUCKET_COUNT = 8
+};
 struct RtMaterial {
     uint32_t type;
     uint32_t tex;     // Lambertian/Isotropic albedo, DiffuseLight emit
