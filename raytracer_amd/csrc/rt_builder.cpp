@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 
 namespace {
 
@@ -646,6 +647,67 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
             for (int c = 0; c < 3; ++c) { acc.lo[c] = std::min(acc.lo[c], bounds[k].lo[c]); acc.hi[c] = std::max(acc.hi[c], bounds[k].hi[c]); }
         }
         tree_ref = next;
+    }
+    // Node numbering: breadth-first from the world's root for the first kBreadthFirst records - the traversal kernel keeps
+    // a prefix of the node array in LDS, and these are the records nearest the root, which every ray visits - then
+    // depth-first (a node followed by its child-0 subtree), which keeps a deep descent within few cache lines.
+    if (!f.nodes.empty()) {
+        const size_t kBreadthFirst = 4096;
+        const uint32_t unset = 0xFFFFFFFFu;
+        std::vector<uint32_t> new_index(f.nodes.size(), unset);
+        uint32_t next_index = 0;
+        std::deque<uint32_t> frontier;
+        std::vector<uint32_t> pending;
+        auto expand = [&](uint32_t ref, auto&& sink) { // hands every node reachable from `ref` without passing through a node to sink
+            std::vector<uint32_t> todo(1, ref);
+            while (!todo.empty()) {
+                const uint32_t r = todo.back(); todo.pop_back();
+                const uint32_t ty = RT_REF_TYPE(r), idx = RT_REF_INDEX(r);
+                if (ty == RT_REF_NODE) sink(idx);
+                else if (ty == RT_REF_INST) todo.push_back(f.insts[idx].child);
+                else if (ty == RT_REF_LIST) {
+                    size_t e = idx;
+                    while (f.list_entries[e] != RT_REF_NONE) ++e;
+                    while (e-- > idx) todo.push_back(f.list_entries[e]);
+                }
+            }
+        };
+        auto claim = [&](uint32_t idx) { if (new_index[idx] != unset) return false; new_index[idx] = next_index++; return true; };
+        expand(tree_ref, [&](uint32_t idx) { if (claim(idx)) frontier.push_back(idx); });
+        while (!frontier.empty() && next_index < kBreadthFirst) {
+            const uint32_t idx = frontier.front(); frontier.pop_front();
+            const uint32_t kids[2] = {f.nodes[idx].c0, f.nodes[idx].c1};
+            for (uint32_t k : kids) expand(k, [&](uint32_t c) { if (claim(c)) frontier.push_back(c); });
+        }
+        // depth-first below whatever the breadth-first part left unexpanded: a node is numbered when it is taken from
+        // the stack, so that its child-0 subtree follows it
+        std::vector<char> seen(f.nodes.size(), 0);
+        for (size_t i = 0; i < seen.size(); ++i) seen[i] = new_index[i] != unset;
+        for (uint32_t start : frontier) {
+            std::vector<uint32_t> stack;
+            auto push_kids = [&](uint32_t idx) {
+                const uint32_t kids[2] = {f.nodes[idx].c1, f.nodes[idx].c0};
+                for (uint32_t k : kids) expand(k, [&](uint32_t c) { if (!seen[c]) { seen[c] = 1; stack.push_back(c); } });
+            };
+            push_kids(start);
+            while (!stack.empty()) {
+                const uint32_t idx = stack.back(); stack.pop_back();
+                new_index[idx] = next_index++;
+                push_kids(idx);
+            }
+        }
+        for (size_t i = 0; i < new_index.size(); ++i) if (new_index[i] == unset) new_index[i] = next_index++; // unreachable from the world's trees
+        std::vector<RtNode> moved(f.nodes.size());
+        auto remap = [&](uint32_t& r) { if (RT_REF_TYPE(r) == RT_REF_NODE) r = RT_MAKE_REF(RT_REF_NODE, new_index[RT_REF_INDEX(r)]); };
+        for (size_t i = 0; i < f.nodes.size(); ++i) {
+            RtNode n = f.nodes[i];
+            remap(n.c0); remap(n.c1);
+            moved[new_index[i]] = n;
+        }
+        f.nodes.swap(moved);
+        for (RtInst& in : f.insts) remap(in.child);
+        for (uint32_t& e : f.list_entries) remap(e);
+        remap(tree_ref);
     }
     const size_t biggest = std::max({f.nodes.size(), f.spheres.size(), f.mspheres.size(), f.rects.size(), f.boxes.size(), f.media.size(),
                                      f.insts.size(), f.list_entries.size()});

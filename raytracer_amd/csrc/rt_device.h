@@ -355,9 +355,14 @@ struct RtTrav {
 // the reference finds depends on exactly which boxes it tests and with which t_max, so those trees are encoded
 // to replay it: child 1 of a node carries the infinite box (entered at t_min, so never before child 0) and leads
 // to a one-child node holding the real right box, which is therefore tested only after the left subtree is done.
-template <class Stack>
-RT_HD void rt_trav_node_step(const DScene& sc, RtTrav& s, Stack& st, double t_min) {
-    const RtNode n = rt_load_node(sc.nodes + RT_REF_INDEX(s.cur));
+// Nodes: RtNode load(uint32_t index) - where node records come from (global memory, or a kernel's cached copy).
+struct GlobalNodes {
+    const RtNode* nodes;
+    RT_HD RtNode load(uint32_t index) const { return rt_load_node(nodes + index); }
+};
+template <class Stack, class Nodes>
+RT_HD void rt_trav_node_step(const Nodes& nodes, RtTrav& s, Stack& st, double t_min) {
+    const RtNode n = nodes.load(RT_REF_INDEX(s.cur));
     double e0, e1;
     const bool h0 = rt_aabb_hit(n.lo0, n.hi0, s.r, s.slab, t_min, s.best.t, e0);
     const bool h1 = rt_aabb_hit(n.lo1, n.hi1, s.r, s.slab, t_min, s.best.t, e1);
@@ -371,10 +376,10 @@ RT_HD void rt_trav_node_step(const DScene& sc, RtTrav& s, Stack& st, double t_mi
         s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop();
     }
 }
-template <class Stack>
-RT_HD void rt_trav_descend(const DScene& sc, RtTrav& s, Stack& st, double t_min) {
+template <class Stack, class Nodes>
+RT_HD void rt_trav_descend(const Nodes& nodes, RtTrav& s, Stack& st, double t_min) {
 #pragma unroll 1
-    while (RT_REF_TYPE(s.cur) == RT_REF_NODE) rt_trav_node_step(sc, s, st, t_min);
+    while (RT_REF_TYPE(s.cur) == RT_REF_NODE) rt_trav_node_step(nodes, s, st, t_min);
 }
 
 template <class Stack, class XiFn, class RayFn>
@@ -419,9 +424,11 @@ RT_HD void rt_traverse(const DScene& sc, uint32_t root, const Ray& r, double t_m
     s.slab = rt_slab_of(r);
     s.best = best;
     s.cur = root;
+    GlobalNodes nodes;
+    nodes.nodes = sc.nodes;
 #pragma unroll 1
     for (;;) {
-        rt_trav_descend(sc, s, st, t_min);
+        rt_trav_descend(nodes, s, st, t_min);
         if (s.cur == RT_REF_NONE) break;
         rt_trav_visit(sc, s, st, t_min, xi, skip_media, world_ray);
     }

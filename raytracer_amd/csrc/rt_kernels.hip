@@ -29,6 +29,7 @@
 #include "rt_device.h"
 
 #define RT_BLOCK 256
+#define RT_TREE_BLOCK 1024 /* k_extend_tree: one workgroup per CU, so that the whole CU shares one LDS copy of the top of the tree */
 #define RT_TREE_CHUNK 1024u /* queue indices a persistent wave reserves per atomic */
 #define RT_BIN_PER_THREAD 8  /* rays per thread in k_bin */
 #define RT_COUNTER_STRIDE 16u /* per iteration: [0] live paths entering it, [1+b] hits queued for shading bucket b, [RT_COUNTER_HEAD] */
@@ -59,15 +60,47 @@ struct QueueSet {
 };
 
 struct LdsStack {
-    uint32_t* base; // this lane's column: entry k at base[k * RT_BLOCK]
-    uint32_t sp, cap;
+    uint32_t* base; // this lane's column: entry k at base[k * stride], stride = threads per block (conflict-free)
+    uint32_t sp, cap, stride;
     uint32_t* error_flag;
     __device__ void push(uint32_t v) {
-        if (sp < cap) { base[sp * RT_BLOCK] = v; ++sp; }
+        if (sp < cap) { base[sp * stride] = v; ++sp; }
         else if (error_flag) atomicOr(error_flag, 1u);
     }
-    __device__ uint32_t pop() { --sp; return base[sp * RT_BLOCK]; }
+    __device__ uint32_t pop() { --sp; return base[sp * stride]; }
     __device__ bool empty() const { return sp == 0u; }
+};
+
+// The first n_cached node records live in LDS, the rest in global memory. A lane fetches a 64-byte record with four
+// 16-byte reads, each lane a different record: through the vector cache that is one tag lookup per lane per read,
+// 256 per wave and node, which is what bounds traversal when the nodes come from global memory. The LDS serves the
+// same reads at its full width. The 16-byte pieces of a record are stored rotated by the record's index so that the
+// lanes of one read spread over all banks.
+struct CachedNodes {
+    const uint4* lds;
+    uint32_t n_cached;
+    const RtNode* global;
+    __device__ static uint32_t place(uint32_t index, uint32_t piece) { return index * 4u + (piece ^ ((index >> 2) & 3u)); }
+    __device__ RtNode load(uint32_t index) const {
+        uint4 a, b, c;
+        uint2 d;
+        if (index < n_cached) {
+            a = lds[place(index, 0u)]; b = lds[place(index, 1u)]; c = lds[place(index, 2u)];
+            d = *(const uint2*)(lds + place(index, 3u));
+        } else {
+            const uint4* g = (const uint4*)(global + index);
+            a = g[0]; b = g[1]; c = g[2];
+            d = *(const uint2*)(g + 3);
+        }
+        RtNode n;
+        n.lo0[0] = __uint_as_float(a.x); n.lo0[1] = __uint_as_float(a.y); n.lo0[2] = __uint_as_float(a.z);
+        n.hi0[0] = __uint_as_float(a.w); n.hi0[1] = __uint_as_float(b.x); n.hi0[2] = __uint_as_float(b.y);
+        n.lo1[0] = __uint_as_float(b.z); n.lo1[1] = __uint_as_float(b.w); n.lo1[2] = __uint_as_float(c.x);
+        n.hi1[0] = __uint_as_float(c.y); n.hi1[1] = __uint_as_float(c.z); n.hi1[2] = __uint_as_float(c.w);
+        n.c0 = d.x; n.c1 = d.y;
+        n.pad[0] = 0u; n.pad[1] = 0u;
+        return n;
+    }
 };
 
 struct PassInfo;
@@ -250,19 +283,31 @@ __global__ void __launch_bounds__(RT_BLOCK) k_extend_flat(DScene sc, PassInfo pi
 //  * box tests run for all lanes that hold a node until `leaf_min` lanes wait at a leaf; then those
 //    leaves are tested together.
 // Which lane traces which ray, and when, has no effect on results.
-__global__ void __launch_bounds__(RT_BLOCK) k_extend_tree(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
-                                                          uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_min,
-                                                          uint32_t seeded) {
-    extern __shared__ uint32_t lds_stack[];
+__global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
+                                                               uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_min,
+                                                               uint32_t seeded, uint32_t n_cached) {
+    extern __shared__ uint4 lds_tree[]; // stack_cap * blockDim.x words of stack, then n_cached node records
     const uint32_t* live = it == 0u ? nullptr : qs.live[it & 1u];
     uint32_t* ctr = qs.counters + it * RT_COUNTER_STRIDE;
     const uint32_t n = ctr[0];
+    if (n == 0u) return;
     uint32_t* head = ctr + RT_COUNTER_HEAD;
     LdsStack st;
-    st.base = lds_stack + threadIdx.x;
+    st.base = (uint32_t*)lds_tree + threadIdx.x;
     st.cap = stack_cap;
+    st.stride = blockDim.x;
     st.error_flag = qs.error_flag;
     st.sp = 0u;
+    CachedNodes nodes;
+    {
+        uint4* cache = lds_tree + (size_t)stack_cap * blockDim.x / 4u;
+        const uint4* src = (const uint4*)sc.nodes;
+        for (uint32_t i = threadIdx.x; i < n_cached * 4u; i += blockDim.x) cache[CachedNodes::place(i >> 2, i & 3u)] = src[i];
+        nodes.lds = cache;
+        nodes.n_cached = n_cached;
+        nodes.global = sc.nodes;
+        __syncthreads();
+    }
     const uint32_t lane = __lane_id();
     RtTrav s;
     s.cur = RT_REF_NONE;
@@ -273,7 +318,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_extend_tree(DScene sc, PassInfo pi
     // the wave draws queue indices from a private chunk and takes a new chunk (one atomic) when it runs out
     // (chunk size: large enough to keep atomics rare, small enough that every wave of the grid gets several)
     uint32_t chunk_next = 0u, chunk_end = 0u;
-    const uint32_t chunk = max(64u, min((uint32_t)RT_TREE_CHUNK, (n / (gridDim.x * (RT_BLOCK / 64u) * 8u)) & ~63u));
+    const uint32_t chunk = max(64u, min((uint32_t)RT_TREE_CHUNK, (n / (gridDim.x * (blockDim.x / 64u) * 8u)) & ~63u));
 #pragma unroll 1
     for (;;) {
         const unsigned long long idle = __ballot(!active);
@@ -314,7 +359,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_extend_tree(DScene sc, PassInfo pi
             const bool at_node = active && RT_REF_TYPE(s.cur) == RT_REF_NODE;
             if (__ballot(at_node) == 0ull) break;
             if ((uint32_t)__popcll(__ballot(active && !at_node)) >= leaf_min) break;
-            if (at_node) rt_trav_node_step(sc, s, st, 0.001);
+            if (at_node) rt_trav_node_step(nodes, s, st, 0.001);
         }
         // ---- one non-node reference for every lane that holds one ----
         if (active && s.cur != RT_REF_NONE && RT_REF_TYPE(s.cur) != RT_REF_NODE) {
@@ -451,6 +496,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_first_hit(DScene sc, const rt_ray_
     LdsStack st;
     st.base = lds_stack + threadIdx.x;
     st.cap = stack_cap;
+    st.stride = RT_BLOCK;
     st.error_flag = error_flag;
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         const rt_ray_d q = rays[i];
@@ -509,6 +555,7 @@ struct rt_context {
     hipStream_t stream = nullptr;
     std::string error;
     int n_cu = 256;
+    size_t lds_per_block = 65536; // most LDS one workgroup may use
     // path pool
     size_t cap_paths = 0;
     double* f64pool = nullptr; // cap_paths PathRay records, then cap_paths PathAcc records
@@ -695,6 +742,10 @@ int rt_init(rt_context** out, int device) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0) ctx->lds_per_block = (size_t)v;
+    }
     if (hipMalloc((void**)&ctx->error_flag, sizeof(uint32_t)) != hipSuccess) {
         hipStreamDestroy(ctx->stream);
         delete ctx;
@@ -868,12 +919,19 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
     local.view.compat = p->compat;
 
     const uint32_t stack_cap = sc->hdr.stack_need;
-    const size_t lds = (size_t)stack_cap * RT_BLOCK * sizeof(uint32_t);
     const bool has_flat = sc->has_flat, has_tree = sc->has_tree;
-    // persistent waves: as many blocks as are resident at once (more would only find the queue empty)
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_extend_tree, RT_BLOCK, lds) != hipSuccess || occ < 1) occ = 2;
-    const uint32_t extend_blocks_per_cu = (uint32_t)occ;
+    // Persistent waves, one workgroup per CU: its LDS holds the traversal stacks and, in what is left, the first
+    // records of the node array (the compiler numbers nodes breadth-first, so these are the ones nearest the root).
+    const size_t lds_stack_bytes = (size_t)stack_cap * RT_TREE_BLOCK * sizeof(uint32_t);
+    if (lds_stack_bytes > ctx->lds_per_block) return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "render: traversal stacks exceed the LDS of a workgroup");
+    const uint32_t n_cached = (uint32_t)std::min<size_t>(sc->hdr.nodes.count, (ctx->lds_per_block - lds_stack_bytes) / sizeof(RtNode));
+    const size_t lds = lds_stack_bytes + (size_t)n_cached * sizeof(RtNode);
+    if (lds > 65536)
+        RT_HIP(hipFuncSetAttribute((const void*)k_extend_tree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size of k_extend_tree");
+    const uint32_t extend_blocks_per_cu = 1u;
+    if (getenv("RT_DEBUG"))
+        fprintf(stderr, "rt: lds_per_block %zu, stack_need %u, nodes %llu, cached %u, lds %zu\n", ctx->lds_per_block, stack_cap,
+                (unsigned long long)sc->hdr.nodes.count, n_cached, lds);
     const size_t n_counters = (size_t)(p->max_depth + 2) * RT_COUNTER_STRIDE;
     std::vector<uint32_t> host_counters(n_counters);
 
@@ -896,7 +954,7 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
         size_t a = tm.begin();
         hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, paths, 8)), dim3(RT_BLOCK), 0, ctx->stream, cd, pi, pb);
         tm.end(a, 0);
-        const uint32_t g_ext = grid_for(ctx, paths, extend_blocks_per_cu);
+        const uint32_t g_ext = (uint32_t)std::max<size_t>(1, std::min<size_t>((paths + RT_TREE_BLOCK - 1) / RT_TREE_BLOCK, (size_t)ctx->n_cu * extend_blocks_per_cu));
         const uint32_t g_sh = grid_for(ctx, paths, 8);
         for (uint32_t it = 0; it < p->max_depth; ++it) {
             if (has_flat) {
@@ -906,8 +964,8 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
             }
             if (has_tree || !has_flat) {
                 a = tm.begin();
-                hipLaunchKernelGGL(k_extend_tree, dim3(g_ext), dim3(RT_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it, stack_cap,
-                                   ctx->tune_refill, ctx->tune_leaf, has_flat ? 1u : 0u);
+                hipLaunchKernelGGL(k_extend_tree, dim3(g_ext), dim3(RT_TREE_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it, stack_cap,
+                                   ctx->tune_refill, ctx->tune_leaf, has_flat ? 1u : 0u, n_cached);
                 tm.end(a, 1);
             }
             a = tm.begin();

@@ -136,10 +136,11 @@ def test_blob_layout_of_the_book2_final_scene():
     assert set(flat[:9].tolist()) <= set(entries[world_first:world_first + 11].tolist())
     # the 2 trees under bounding nodes: top = {the BVH of boxes (node 0), next = {the Translate instance, nothing}}
     nodes = nodes_of(blob, h)
-    assert (h["world_tree"] >> 28) == 1
-    top = nodes[h["world_tree"] & 0x03FFFFFF]
-    assert top["c0"] == (1 << 28) | 0 and (top["c1"] >> 28) == 1
-    wrap = nodes[top["c1"] & 0x03FFFFFF]
+    # nodes are numbered breadth-first from the world's root
+    assert h["world_tree"] == (1 << 28) | 0
+    top = nodes[0]
+    assert top["c0"] == (1 << 28) | 1 and top["c1"] == (1 << 28) | 2
+    wrap = nodes[2]
     assert (wrap["c0"] >> 28) == 7 and wrap["c1"] == 0 and is_empty(wrap["lo1"], wrap["hi1"])
     # the instanced cluster: spheres r=10 with centres in [0,165)^3, rotated 15 degrees about y, moved by (-100,270,395)
     assert np.all(wrap["lo0"] < [-100, 265, 345]) and np.all(wrap["hi0"] > [60, 430, 540])
@@ -159,12 +160,13 @@ def test_cornell_replays_the_reference_order():
     assert h["sections"]["rects"][1] == 6 and h["sections"]["boxes"][1] == 2
     # its RotateY instances keep unrotated boxes: no record below the world's may leave the order to the ray
     # (child 1 is absent, or is entered at t_min like nothing else can be)
-    for i, n in enumerate(nodes[:-1]):
+    assert h["world_tree"] == (1 << 28) | 0
+    for i, n in enumerate(nodes[1:]):
         assert is_empty(n["lo1"], n["hi1"]) if n["c1"] == 0 else is_infinite(n["lo1"], n["hi1"]), i
-    top = nodes[h["world_tree"] & 0x03FFFFFF]
-    assert top["c0"] == (1 << 28) | 0 and top["c1"] == 0
-    root_gate = nodes[0]
-    assert root_gate["c0"] == (1 << 28) | 1 and root_gate["c1"] == 0
+    top = nodes[0]
+    assert top["c0"] == (1 << 28) | 1 and top["c1"] == 0
+    root_gate = nodes[1]
+    assert root_gate["c0"] == (1 << 28) | 2 and root_gate["c1"] == 0
     assert np.all(root_gate["lo0"] <= [0, 0, 0]) and np.all(root_gate["hi0"] >= [555, 555, 555]) and np.all(root_gate["hi0"] < 556)
 
 
@@ -209,10 +211,15 @@ def test_tree_boxes_contain_and_hug_their_subtrees(flags):
     lo, hi = bounds(int(top["c0"]))
     assert top["c1"] == 0 and np.all(top["lo0"] < lo) and np.all(top["hi0"] > hi) and np.all(top["hi0"] - hi < 0.01)
     assert sorted(seen) == list(range(257))          # every sphere under exactly one leaf
-    # depth-first pre-order: child 0, when it is a node, is the next record
-    for i, n in enumerate(nodes[:-1]):
-        if n["c0"] >> 28 == 1:
-            assert (n["c0"] & 0x03FFFFFF) == i + 1
+    # breadth-first numbering from the world's root: children always come after their parent, level by level
+    assert h["world_tree"] == (1 << 28) | 0
+    expect = 1
+    for i, n in enumerate(nodes):
+        for cref in (int(n["c0"]), int(n["c1"])):
+            if cref >> 28 == 1:
+                assert (cref & 0x03FFFFFF) == expect
+                expect += 1
+    assert expect == len(nodes)
 
 
 def test_description_log_replays_to_the_same_scene_twice():
