@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 
 namespace {
 
@@ -149,12 +150,27 @@ bool rt_builder::bounding_box(int h, double t0, double t1, AABB& out) const {
     return false;
 }
 
-// Bounds, in the frame `h` lives in, of everything a ray can hit below `h`, for the objects that own a tree: a
-// BvhNode's box, carried outward through Translate / RotateY (rotating the box, which the reference's RotateY
-// computes and drops, hittable.rs:117-143). false = unknown (treated as unbounded).
+// Bounds, in the frame `h` lives in, of everything a ray can hit below `h` - true bounds, not the reference's
+// bounding_box(): a BvhNode's box and a primitive's own box are taken as they are, a box carried outward through
+// RotateY is really rotated (the reference's RotateY computes that box and drops it, hittable.rs:117-143), a list is
+// the union of its members, a medium is its boundary. false = unknown (treated as unbounded): a moving sphere, whose
+// extent depends on the shutter interval of the camera that will be used.
 bool rt_builder::world_bound(int h, AABB& out) const {
     const ObjRec& o = objs[h];
     if (o.kind == OBJ_BVH) { out = o.box; return true; }
+    if (o.kind == OBJ_SPHERE || o.kind == OBJ_XYRECT || o.kind == OBJ_XZRECT || o.kind == OBJ_YZRECT || o.kind == OBJ_BOX)
+        return bounding_box(h, 0.0, 0.0, out);
+    if (o.kind == OBJ_MEDIUM) return world_bound(o.child, out);
+    if (o.kind == OBJ_LIST) {
+        if (o.members.empty()) return false;
+        for (int i = 0; i < 3; ++i) { out.lo[i] = kInf; out.hi[i] = -kInf; }
+        for (int m : o.members) {
+            AABB c;
+            if (!world_bound(m, c)) return false;
+            for (int i = 0; i < 3; ++i) { out.lo[i] = std::min(out.lo[i], c.lo[i]); out.hi[i] = std::max(out.hi[i], c.hi[i]); }
+        }
+        return true;
+    }
     if (o.kind == OBJ_TRANSLATE) {
         if (!world_bound(o.child, out)) return false;
         for (int i = 0; i < 3; ++i) { out.lo[i] += o.d[i]; out.hi[i] += o.d[i]; }
@@ -457,8 +473,9 @@ Kid build_sah(std::vector<TNode>& tree, std::vector<SahItem>& items, size_t star
 }
 
 // A tree whose boxes all bound their contents: real boxes on both children, walked nearest first.
-static uint32_t emit_ordered(rt_builder* b, rt_builder::Flat& f, const std::vector<TNode>& tree, const Kid& k, int parent,
-                             uint32_t depth, uint32_t& need);
+// leaf(obj, need) emits object `obj` of the tree and returns its ref.
+typedef std::function<uint32_t(int, uint32_t&)> LeafFn;
+static uint32_t emit_ordered(rt_builder::Flat& f, const std::vector<TNode>& tree, const Kid& k, const LeafFn& leaf, uint32_t& need);
 
 uint32_t rt_builder::emit_bvh(Flat& f, const ObjRec& o, int parent, uint32_t depth, uint32_t& need) {
     if (o.exact_bounds) {
@@ -488,7 +505,7 @@ uint32_t rt_builder::emit_bvh(Flat& f, const ObjRec& o, int parent, uint32_t dep
             }
             root = build_sah(tree, items, 0, items.size(), 0);
         }
-        return emit_ordered(this, f, tree, root, parent, depth, need);
+        return emit_ordered(f, tree, root, [&](int obj, uint32_t& n) { return emit(f, obj, parent, depth, n); }, need);
     }
     // Replay form: the root's own box first (bvh.rs:113), in front of the root node.
     const uint32_t gate = (uint32_t)f.nodes.size();
@@ -500,19 +517,18 @@ uint32_t rt_builder::emit_bvh(Flat& f, const ObjRec& o, int parent, uint32_t dep
     return RT_MAKE_REF(RT_REF_NODE, gate);
 }
 
-static uint32_t emit_ordered(rt_builder* b, rt_builder::Flat& f, const std::vector<TNode>& tree, const Kid& k, int parent,
-                             uint32_t depth, uint32_t& need) {
+static uint32_t emit_ordered(rt_builder::Flat& f, const std::vector<TNode>& tree, const Kid& k, const LeafFn& leaf, uint32_t& need) {
     need = 0;
-    if (k.node < 0) return k.obj >= 0 ? b->emit(f, k.obj, parent, depth, need) : (uint32_t)RT_REF_NONE;
+    if (k.node < 0) return k.obj >= 0 ? leaf(k.obj, need) : (uint32_t)RT_REF_NONE;
     const uint32_t me = (uint32_t)f.nodes.size();
     f.nodes.push_back(blank_node());
     const TNode& t = tree[(size_t)k.node];
     uint32_t n0 = 0, n1 = 0;
-    const uint32_t c0 = emit_ordered(b, f, tree, t.kid[0], parent, depth, n0);
+    const uint32_t c0 = emit_ordered(f, tree, t.kid[0], leaf, n0);
     if (c0 == RT_REF_NONE) return RT_REF_NONE;
     uint32_t c1 = RT_REF_NONE;
     if (t.kid[1].node >= 0 || t.kid[1].obj >= 0) {
-        c1 = emit_ordered(b, f, tree, t.kid[1], parent, depth, n1);
+        c1 = emit_ordered(f, tree, t.kid[1], leaf, n1);
         if (c1 == RT_REF_NONE) return RT_REF_NONE;
     }
     RtNode& n = f.nodes[me];
@@ -572,41 +588,88 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     if (!blob_out || !nbytes) return fail(RT_ERR_INVALID, "null output");
     if (!valid_obj(world)) return fail(RT_ERR_INVALID, "world handle %d is not a hittable", world);
     Flat f;
-    uint32_t need = 0;
-    uint32_t wref;
-    if (objs[world].kind == OBJ_LIST) {
-        wref = emit(f, world, RT_NO_PARENT, 0, need);
-    } else { // ray_color takes a HittableList (main.rs:49): wrap anything else in a one-entry list
-        uint32_t cneed;
-        uint32_t r = emit(f, world, RT_NO_PARENT, 0, cneed);
-        if (r == RT_REF_NONE) return RT_ERR_UNSUPPORTED;
-        const uint32_t first = (uint32_t)f.list_entries.size();
-        f.list_entries.push_back(r);
-        f.list_entries.push_back(RT_REF_NONE);
-        need = std::max(2u, 1u + cneed);
-        wref = RT_MAKE_REF(RT_REF_LIST, first);
-    }
-    if (wref == RT_REF_NONE) return error.empty() ? fail(RT_ERR_UNSUPPORTED, "empty scene") : RT_ERR_UNSUPPORTED;
-    // The closest hit does not depend on the order in which the world's entries are tested (only exact ties do), so the
-    // kernels test the entries that are plain primitives or media first, in lock step, and then walk the rest per lane.
-    // The rest (BvhNodes, possibly under Translate/RotateY, nested lists) is hung under a chain of extra nodes
-    //     T_k = { child 0: entry k under its world-space bound, child 1: T_k+1 under the union of the bounds of entries k+1.. }
-    // so that per-lane work is box tests only: an entry whose world-space bound the ray misses costs one box test
-    // instead of an instance entry/exit. The extra boxes are supersets of what the entry's own root box admits (with
-    // a 1e-6 relative margin against the rounding of the frame change), so they never cull a hit the reference finds.
-    std::vector<uint32_t> flat_refs, tree_refs;
-    std::vector<int> tree_handles;
+    // world.hit (hittable_list.rs:40-53) returns the closest hit over the world's entries, and that does not depend on
+    // the order the entries are tested in or on which of them are skipped because the ray misses their bounds (only
+    // exact ties do). So the compiler is free to arrange the entries for the hardware:
+    //  * a BvhNode entry whose boxes all bound their contents is dissolved into its objects (unless the caller asked
+    //    for reference trees);
+    //  * every entry with known, finite bounds that is not huge against the rest goes under ONE surface-area-heuristic
+    //    tree, walked per lane with a stack (`world_tree`): primitives, media (a ray that misses the boundary's bounds
+    //    cannot scatter in it, constant_medium.rs:29-35), Translate/RotateY instances, trees that must keep the
+    //    reference's order;
+    //  * the rest - unbounded (a moving sphere: its extent depends on the camera's shutter) or so large that nearly
+    //    every ray meets it anyway (a medium filling the scene, a ground sphere) - is tested by every lane in lock
+    //    step (`world_flat`), which costs no divergence;
+    //  * an entry that is neither boundable nor testable in lock step (a nested list holding a moving sphere) is chained
+    //    in front of the tree under the infinite box.
+    // Bounds of anything seen through an instance carry a 1e-6 relative margin against the rounding of the frame change.
+    struct Item { int handle; bool bounded; AABB box; bool flatable; };
+    std::vector<Item> items;
     {
         std::vector<int> members;
         if (objs[world].kind == OBJ_LIST) members = objs[world].members; else members.push_back(world);
-        uint32_t i = RT_REF_INDEX(wref);
-        for (size_t k = 0; k < members.size(); ++k, ++i) {
-            uint32_t e = f.list_entries[i], leaf = e;
-            while (RT_REF_TYPE(leaf) == RT_REF_INST) leaf = f.insts[RT_REF_INDEX(leaf)].child;
-            const uint32_t ty = RT_REF_TYPE(leaf);
-            if (ty == RT_REF_NODE || ty == RT_REF_LIST) { tree_refs.push_back(e); tree_handles.push_back(members[k]); }
-            else flat_refs.push_back(e);
+        auto flatable = [&](int h) { // a primitive or medium under at most RT_MAX_CHAIN instances
+            uint32_t chain = 0;
+            while (objs[h].kind == OBJ_TRANSLATE || objs[h].kind == OBJ_ROTATE_Y) { h = objs[h].child; ++chain; }
+            return objs[h].kind != OBJ_BVH && objs[h].kind != OBJ_LIST && chain <= RT_MAX_CHAIN;
+        };
+        for (int m : members) {
+            const ObjRec& o = objs[m];
+            if (o.kind == OBJ_BVH && o.exact_bounds && !(flags & RT_BLOB_FLAG_REFERENCE_TREE)) {
+                for (int sub : objs[o.child].members) {
+                    Item it;
+                    it.handle = sub; it.flatable = flatable(sub);
+                    it.bounded = bounding_box(sub, o.d[0], o.d[1], it.box);
+                    if (!it.bounded) return fail(RT_ERR_PANIC, "No bounding box");
+                    items.push_back(it);
+                }
+                continue;
+            }
+            Item it;
+            it.handle = m;
+            it.flatable = flatable(m);
+            it.bounded = world_bound(m, it.box);
+            if (it.bounded) {
+                for (int c = 0; c < 3; ++c) {
+                    if (!(std::fabs(it.box.lo[c]) < kInf) || !(std::fabs(it.box.hi[c]) < kInf)) { it.bounded = false; break; }
+                    const double mg = 1e-6 * std::max(std::max(std::fabs(it.box.lo[c]), std::fabs(it.box.hi[c])), it.box.hi[c] - it.box.lo[c]) + 1e-9;
+                    it.box.lo[c] -= mg; it.box.hi[c] += mg;
+                }
+            }
+            items.push_back(it);
         }
+    }
+    if (items.empty()) return fail(RT_ERR_UNSUPPORTED, "empty scene");
+    // huge = at least as large as everything smaller than it put together: peel such items off, largest first
+    std::vector<char> in_tree(items.size(), 0);
+    {
+        std::vector<size_t> order;
+        for (size_t i = 0; i < items.size(); ++i) if (items[i].bounded) order.push_back(i);
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return half_area(items[a].box) < half_area(items[b].box); });
+        AABB acc = kEmptyBox;
+        for (size_t k = 0; k < order.size(); ++k) { // ascending: acc = union of everything smaller
+            const Item& it = items[order[k]];
+            const bool huge = it.flatable && k > 0 && half_area(it.box) >= 4.0 * half_area(acc);
+            if (!huge) { in_tree[order[k]] = 1; acc = box_union(acc, it.box); }
+        }
+    }
+    std::vector<uint32_t> flat_refs, loose_refs;
+    std::vector<SahItem> sah;
+    uint32_t need = 0;
+    for (size_t i = 0; i < items.size(); ++i) {
+        const Item& it = items[i];
+        if (in_tree[i]) {
+            SahItem si;
+            si.obj = it.handle; si.box = it.box;
+            for (int a = 0; a < 3; ++a) si.c[a] = 0.5 * (it.box.lo[a] + it.box.hi[a]);
+            sah.push_back(si);
+            continue;
+        }
+        uint32_t n = 0;
+        const uint32_t r = emit(f, it.handle, RT_NO_PARENT, 0, n);
+        if (r == RT_REF_NONE) return error.empty() ? fail(RT_ERR_UNSUPPORTED, "empty scene") : RT_ERR_UNSUPPORTED;
+        if (it.flatable) flat_refs.push_back(r);
+        else { loose_refs.push_back(r); need = std::max(need, n); }
     }
     uint32_t flat_ref = RT_REF_NONE, tree_ref = RT_REF_NONE;
     if (!flat_refs.empty()) {
@@ -614,39 +677,27 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         for (uint32_t r : flat_refs) f.list_entries.push_back(r);
         f.list_entries.push_back(RT_REF_NONE);
     }
-    if (!tree_refs.empty()) {
-        struct FBox { float lo[3], hi[3]; };
-        std::vector<FBox> bounds(tree_refs.size());
-        for (size_t k = 0; k < tree_refs.size(); ++k) {
-            AABB wb;
-            FBox& n = bounds[k];
-            if (world_bound(tree_handles[k], wb)) {
-                for (int c = 0; c < 3; ++c) {
-                    const double m = 1e-6 * std::max(std::max(std::fabs(wb.lo[c]), std::fabs(wb.hi[c])), wb.hi[c] - wb.lo[c]) + 1e-9;
-                    n.lo[c] = round_down_f32(wb.lo[c] - m);
-                    n.hi[c] = round_up_f32(wb.hi[c] + m);
-                }
-            } else {
-                set_box_all(n.lo, n.hi);
-            }
+    if (!sah.empty()) {
+        std::vector<TNode> tree;
+        Kid root = build_sah(tree, sah, 0, sah.size(), 0);
+        if (root.node < 0) { // a single item still needs a node to carry its box
+            tree.push_back(TNode());
+            tree[0].kid[0] = root;
+            root.node = 0; root.obj = -1;
         }
-        // built back to front so that T_k can point at T_k+1
-        uint32_t next = RT_REF_NONE;
-        FBox acc;
-        set_box_empty(acc.lo, acc.hi);
-        for (size_t k = tree_refs.size(); k-- > 0;) {
-            RtNode t = blank_node();
-            for (int c = 0; c < 3; ++c) { t.lo0[c] = bounds[k].lo[c]; t.hi0[c] = bounds[k].hi[c]; }
-            t.c0 = tree_refs[k];
-            if (next != RT_REF_NONE) {
-                for (int c = 0; c < 3; ++c) { t.lo1[c] = acc.lo[c]; t.hi1[c] = acc.hi[c]; }
-                t.c1 = next;
-            }
-            f.nodes.push_back(t);
-            next = RT_MAKE_REF(RT_REF_NODE, f.nodes.size() - 1);
-            for (int c = 0; c < 3; ++c) { acc.lo[c] = std::min(acc.lo[c], bounds[k].lo[c]); acc.hi[c] = std::max(acc.hi[c], bounds[k].hi[c]); }
-        }
-        tree_ref = next;
+        uint32_t n = 0;
+        tree_ref = emit_ordered(f, tree, root, [&](int obj, uint32_t& ln) { return emit(f, obj, RT_NO_PARENT, 0, ln); }, n);
+        if (tree_ref == RT_REF_NONE) return error.empty() ? fail(RT_ERR_UNSUPPORTED, "empty scene") : RT_ERR_UNSUPPORTED;
+        need = std::max(need, n);
+    }
+    for (size_t k = loose_refs.size(); k-- > 0;) { // T = { child 0: the entry, always entered; child 1: what was built so far }
+        RtNode t = blank_node();
+        set_box_all(t.lo0, t.hi0);
+        t.c0 = loose_refs[k];
+        if (tree_ref != RT_REF_NONE) { set_box_all(t.lo1, t.hi1); t.c1 = tree_ref; }
+        f.nodes.push_back(t);
+        tree_ref = RT_MAKE_REF(RT_REF_NODE, f.nodes.size() - 1);
+        need += 1u;
     }
     // Node numbering: breadth-first from the world's root for the first kBreadthFirst records - the traversal kernel keeps
     // a prefix of the node array in LDS, and these are the records nearest the root, which every ray visits - then
@@ -770,7 +821,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     blob.resize((blob.size() + 255u) & ~(size_t)255u);
     hd.magic = RT_BLOB_MAGIC; hd.version = RT_BLOB_VERSION;
     hd.total_bytes = blob.size();
-    hd.world = wref;
+    hd.world = RT_REF_NONE;
     hd.world_flat = flat_ref;
     hd.world_tree = tree_ref;
     hd.n_media = (uint32_t)n_media;

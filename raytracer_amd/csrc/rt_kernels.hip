@@ -209,6 +209,10 @@ struct SlotRay { // the world-space ray of a path, re-read from the path buffers
     uint32_t slot;
     __device__ Ray operator()() const { return load_ray(*pb, slot); }
 };
+struct HeldRay { // the world-space ray, still held in registers
+    const Ray* r;
+    __device__ Ray operator()() const { return *r; }
+};
 struct QueryRay {
     const rt_ray_d* q;
     __device__ Ray operator()() const {
@@ -249,32 +253,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtCameraDev cam, PassInfo p
     }
 }
 
-// world.hit(r, 0.001, INFINITY, rec) (main.rs:56) for every live path of iteration `it`, in three launches:
+// world.hit(r, 0.001, INFINITY, rec) (main.rs:56) for every live path of iteration `it`, in two launches:
 //
-//   k_extend_flat   the world entries that are plain primitives or media, every lane in lock step
-//   k_extend_tree   the world entries that are BVHs, per lane with a stack, persistent waves (below)
-//   k_bin           misses take the background and end; hits are queued by material type
-//
-// The closest hit is the minimum over all entries whatever the order they are tested in, so the flat pass
-// seeds pb.hit[slot] and the tree pass only improves on it.
-
-__global__ void __launch_bounds__(RT_BLOCK) k_extend_flat(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it) {
-    const uint32_t* live = it == 0u ? nullptr : qs.live[it & 1u];
-    const uint32_t n = qs.counters[it * RT_COUNTER_STRIDE];
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
-        const uint32_t slot = live ? live[i] : i;
-        SlotRay ray_of;
-        ray_of.pb = &pb; ray_of.slot = slot;
-        PhiloxXi xi;
-        xi.pi = &pi; xi.slot = slot; xi.bounce = it;
-        RtBest best;
-        best.t = RT_INF; best.ref = RT_REF_NONE; best.aux = 0u;
-        rt_extend_flat(sc, ray_of, 0.001, best, xi, false);
-        RtHitLite h;
-        h.t = best.t; h.ref = best.ref; h.aux = best.aux;
-        pb.hit[slot] = h;
-    }
-}
+//   k_extend_tree   closest hit: the lock-step entries when a lane takes a ray, then the tree, persistent waves
+//   k_bin           misses take the background and end; hits are queued by material type and texture class
 
 // Persistent waves. Once rays are incoherent the number of box tests differs by an order of magnitude from
 // lane to lane, and box tests and leaf tests interleave differently in every lane. So:
@@ -285,7 +267,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_extend_flat(DScene sc, PassInfo pi
 // Which lane traces which ray, and when, has no effect on results.
 __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
                                                                uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_min,
-                                                               uint32_t seeded, uint32_t n_cached) {
+                                                               uint32_t n_cached) {
     extern __shared__ uint4 lds_tree[]; // stack_cap * blockDim.x words of stack, then n_cached node records
     const uint32_t* live = it == 0u ? nullptr : qs.live[it & 1u];
     uint32_t* ctr = qs.counters + it * RT_COUNTER_STRIDE;
@@ -338,13 +320,14 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
                 if (i < n && i < chunk_end) {
                     slot = live ? live[i] : i;
                     s.r = load_ray(pb, slot);
+                    s.best.t = RT_INF; s.best.ref = RT_REF_NONE; s.best.aux = 0u;
+                    // the world entries every ray is tested against, by the lanes that just took a ray, in lock step
+                    HeldRay held;
+                    held.r = &s.r;
+                    PhiloxXi xi;
+                    xi.pi = &pi; xi.slot = slot; xi.bounce = it;
+                    rt_extend_flat(sc, held, 0.001, s.best, xi, false);
                     s.slab = rt_slab_of(s.r);
-                    if (seeded) {
-                        const RtHitLite h = pb.hit[slot];
-                        s.best.t = h.t; s.best.ref = h.ref; s.best.aux = h.aux;
-                    } else {
-                        s.best.t = RT_INF; s.best.ref = RT_REF_NONE; s.best.aux = 0u;
-                    }
                     s.cur = sc.world_tree;
                     st.sp = 0u;
                     active = true;
@@ -919,7 +902,6 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
     local.view.compat = p->compat;
 
     const uint32_t stack_cap = sc->hdr.stack_need;
-    const bool has_flat = sc->has_flat, has_tree = sc->has_tree;
     // Persistent waves, one workgroup per CU: its LDS holds the traversal stacks and, in what is left, the first
     // records of the node array (the compiler numbers nodes breadth-first, so these are the ones nearest the root).
     const size_t lds_stack_bytes = (size_t)stack_cap * RT_TREE_BLOCK * sizeof(uint32_t);
@@ -957,17 +939,10 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
         const uint32_t g_ext = (uint32_t)std::max<size_t>(1, std::min<size_t>((paths + RT_TREE_BLOCK - 1) / RT_TREE_BLOCK, (size_t)ctx->n_cu * extend_blocks_per_cu));
         const uint32_t g_sh = grid_for(ctx, paths, 8);
         for (uint32_t it = 0; it < p->max_depth; ++it) {
-            if (has_flat) {
-                a = tm.begin();
-                hipLaunchKernelGGL(k_extend_flat, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);
-                tm.end(a, 8);
-            }
-            if (has_tree || !has_flat) {
-                a = tm.begin();
-                hipLaunchKernelGGL(k_extend_tree, dim3(g_ext), dim3(RT_TREE_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it, stack_cap,
-                                   ctx->tune_refill, ctx->tune_leaf, has_flat ? 1u : 0u, n_cached);
-                tm.end(a, 1);
-            }
+            a = tm.begin();
+            hipLaunchKernelGGL(k_extend_tree, dim3(g_ext), dim3(RT_TREE_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it, stack_cap,
+                               ctx->tune_refill, ctx->tune_leaf, n_cached);
+            tm.end(a, 1);
             a = tm.begin();
             hipLaunchKernelGGL(k_bin, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);
             tm.end(a, 9);
@@ -993,6 +968,11 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
             uint64_t seg = 0;
             for (uint32_t it = 0; it < p->max_depth; ++it) seg += host_counters[(size_t)it * RT_COUNTER_STRIDE];
             stats->ray_segments += seg;
+            if (getenv("RT_DEBUG")) {
+                fprintf(stderr, "rt: live paths per bounce:");
+                for (uint32_t it = 0; it < p->max_depth; ++it) fprintf(stderr, " %u", host_counters[(size_t)it * RT_COUNTER_STRIDE]);
+                fprintf(stderr, "\n");
+            }
             stats->medium_tests += seg * sc->hdr.n_media;
             for (const EventTimer::Span& sp : tm.spans) {
                 float ms = 0.f;

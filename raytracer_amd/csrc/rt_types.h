@@ -117,9 +117,9 @@ struct RtSection { uint64_t offset; uint64_t count; };
 struct RtBlobHeader {
     uint32_t magic, version;
     uint64_t total_bytes;
-    uint32_t world;          // ref of the world HittableList (main.rs:49 takes &Arc<HittableList>), entries in the reference's order
-    uint32_t world_flat;     // LIST ref (or NONE): the world entries that are a primitive or medium, possibly under Translate/RotateY; tested by every lane in lock step
-    uint32_t world_tree;     // NODE ref (or NONE): the remaining world entries (BvhNodes, instances of them, nested lists) under a chain of bounding nodes; walked per lane with a stack
+    uint32_t world;          // unused (NONE)
+    uint32_t world_flat;     // LIST ref (or NONE): the world entries (primitives or media, possibly under Translate/RotateY) that every lane tests in lock step: unbounded or huge ones
+    uint32_t world_tree;     // NODE ref (or NONE): everything else of the world under one tree; walked per lane with a stack
     uint32_t n_media;        // number of ConstantMedium objects == free-flight draws per segment
     uint32_t stack_need;     // worst-case traversal stack depth for this scene
     uint32_t max_chain;      // deepest instance nesting

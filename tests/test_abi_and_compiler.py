@@ -116,38 +116,37 @@ def test_blob_layout_of_the_book2_final_scene():
     h = header(blob)
     assert h["magic"] == 0x31425452 and h["total"] == len(blob) and len(blob) % 256 == 0
     s = h["sections"]
-    # one node per internal split, one object per leaf: 400 boxes -> 399 nodes, 1000 spheres -> 999,
-    # + one bounding node per tree of the world list
-    assert s["nodes"][1] == 399 + 999 + 2
+    # The world list holds 11 entries (main.rs:576-688). Two are tested by every lane in lock step: the moving sphere
+    # (unbounded until the camera's shutter is known) and the r=5000 medium that contains the whole scene. The BvhNode
+    # of 400 boxes is dissolved; its boxes and the other 8 entries (7 primitives / media + the instanced cluster) form
+    # one tree of 408 leaves = 407 nodes; the cluster's own tree over 1000 spheres has 999.
+    assert s["nodes"][1] == 407 + 999
     assert s["boxes"][1] == 400 and s["mspheres"][1] == 1 and s["rects"][1] == 1
     assert s["spheres"][1] == 1000 + 5 + 2            # + the two medium boundaries (one is the shared r=70 sphere again)
     assert s["media"][1] == 2 == h["n_media"] and s["insts"][1] == 2 and h["max_chain"] == 2
     assert s["texels"][1] == 1024 * 512 * 3 and s["perlin_vec"][1] == 768 and s["perlin_perm"][1] == 768
     assert all(off % 256 == 0 for off, _ in s.values())
     assert 2 <= h["stack_need"] <= 40
-    # world list: 11 entries then the terminator
-    world_first = h["world"] & 0x03FFFFFF
     entries = np.frombuffer(blob, dtype="<u4", count=s["list_entries"][1], offset=s["list_entries"][0])
-    assert (h["world"] >> 28) == 8 and np.count_nonzero(entries[world_first:world_first + 11]) == 11 and entries[world_first + 11] == 0
-    # the 9 entries that are primitives / media, as a list of their own
     flat_first = h["world_flat"] & 0x03FFFFFF
-    flat = entries[flat_first:flat_first + 10]
-    assert (h["world_flat"] >> 28) == 8 and np.count_nonzero(flat[:9]) == 9 and flat[9] == 0
-    assert set(flat[:9].tolist()) <= set(entries[world_first:world_first + 11].tolist())
-    # the 2 trees under bounding nodes: top = {the BVH of boxes (node 0), next = {the Translate instance, nothing}}
-    nodes = nodes_of(blob, h)
+    flat = entries[flat_first:flat_first + 3]
+    assert (h["world_flat"] >> 28) == 8 and flat[2] == 0 and sorted(int(e) >> 28 for e in flat[:2]) == [3, 6]
     # nodes are numbered breadth-first from the world's root
+    nodes = nodes_of(blob, h)
     assert h["world_tree"] == (1 << 28) | 0
     top = nodes[0]
-    assert top["c0"] == (1 << 28) | 1 and top["c1"] == (1 << 28) | 2
-    wrap = nodes[2]
-    assert (wrap["c0"] >> 28) == 7 and wrap["c1"] == 0 and is_empty(wrap["lo1"], wrap["hi1"])
-    # the instanced cluster: spheres r=10 with centres in [0,165)^3, rotated 15 degrees about y, moved by (-100,270,395)
-    assert np.all(wrap["lo0"] < [-100, 265, 345]) and np.all(wrap["hi0"] > [60, 430, 540])
-    assert np.all(wrap["lo0"] > [-170, 250, 330]) and np.all(wrap["hi0"] < [130, 450, 620])
-    assert np.array_equal(top["lo1"], wrap["lo0"]) and np.array_equal(top["hi1"], wrap["hi0"])
-    # the 400 ground boxes: x, z in [-1000, 1000], tops below 101
-    assert np.all(top["lo0"] <= [-1000, 0, -1000]) and np.all(top["hi0"] >= [1000, 1, 1000]) and top["hi0"][1] < 102
+    lo = np.minimum(top["lo0"], top["lo1"])
+    hi = np.maximum(top["hi0"], top["hi1"])
+    # everything in the tree: ground boxes x, z in [-1000, 1000), the light at y = 554, the cluster up to z < 620
+    assert np.all(lo <= [-1000, 0, -1000]) and np.all(lo > [-1001, -1, -1001])
+    assert np.all(hi >= [1000 - 1, 554, 1000 - 1]) and np.all(hi < [1001, 600, 1001])
+    # the instanced cluster hangs under some node as a Translate instance with its world-space bound:
+    # spheres r=10 with centres in [0,165)^3, rotated 15 degrees about y, moved by (-100,270,395)
+    found = [(n["lo0"], n["hi0"]) for n in nodes if n["c0"] >> 28 == 7] + [(n["lo1"], n["hi1"]) for n in nodes if n["c1"] >> 28 == 7]
+    assert len(found) == 1
+    wlo, whi = found[0]
+    assert np.all(wlo < [-100, 265, 345]) and np.all(whi > [60, 430, 540])
+    assert np.all(wlo > [-170, 250, 330]) and np.all(whi < [130, 450, 620])
 
 
 def test_cornell_replays_the_reference_order():
@@ -184,7 +183,7 @@ def test_tree_boxes_contain_and_hug_their_subtrees(flags):
     so, sn = h["sections"]["spheres"]
     sph = np.frombuffer(blob, dtype="<f8", count=sn * 4, offset=so).reshape(sn, 4)
     if flags == 0:
-        assert len(nodes) == 256 + 1     # one object per leaf; + the world's bounding node
+        assert len(nodes) == 256         # the BvhNode is dissolved into the world's tree: one object per leaf
     seen = []
 
     def bounds(ref):
@@ -207,9 +206,12 @@ def test_tree_boxes_contain_and_hug_their_subtrees(flags):
             assert np.all(hi32.astype(np.float64) - hi <= np.spacing(np.abs(hi32)).astype(np.float64))
             out = (lo, hi) if out is None else (np.minimum(out[0], lo), np.maximum(out[1], hi))
         return out
-    top = nodes[h["world_tree"] & 0x03FFFFFF]       # the world's bounding node keeps a margin (frame changes round)
-    lo, hi = bounds(int(top["c0"]))
-    assert top["c1"] == 0 and np.all(top["lo0"] < lo) and np.all(top["hi0"] > hi) and np.all(top["hi0"] - hi < 0.01)
+    if flags == 0:
+        bounds(h["world_tree"])
+    else:
+        top = nodes[h["world_tree"] & 0x03FFFFFF]   # a BvhNode kept whole is a leaf of the world's tree: its bound has a margin
+        lo, hi = bounds(int(top["c0"]))
+        assert top["c1"] == 0 and np.all(top["lo0"] < lo) and np.all(top["hi0"] > hi) and np.all(top["hi0"] - hi < 0.01)
     assert sorted(seen) == list(range(257))          # every sphere under exactly one leaf
     # breadth-first numbering from the world's root: children always come after their parent, level by level
     assert h["world_tree"] == (1 << 28) | 0
@@ -231,7 +233,7 @@ def test_description_log_replays_to_the_same_scene_twice():
 def test_one_million_sphere_scene_compiles():
     b, info, blob, _ = util.build_scene("spheres_grid", n=1_000_000)
     h = header(blob)
-    # 1,000,001 objects, one per leaf -> 1,000,000 nodes, + the world's bounding node
-    assert h["sections"]["nodes"][1] == 1_000_001
+    # the ground sphere is tested in lock step; 1,000,000 spheres, one per leaf -> 999,999 nodes
+    assert h["sections"]["nodes"][1] == 999_999 and h["world_flat"] >> 28 == 8
     assert h["sections"]["spheres"][1] + h["sections"]["mspheres"][1] == 1_000_001
     assert h["stack_need"] <= 40 and info.width == 3840 and info.height == 2160
