@@ -30,10 +30,8 @@
 
 #define RT_BLOCK 256
 #define RT_TREE_BLOCK 1024 /* k_extend_tree: one workgroup per CU, so that the whole CU shares one LDS copy of the top of the tree */
-#define RT_TREE_CHUNK 1024u /* queue indices a persistent wave reserves per atomic */
 #define RT_BIN_PER_THREAD 8  /* rays per thread in k_bin */
-#define RT_COUNTER_STRIDE 16u /* per iteration: [0] live paths entering it, [1+b] hits queued for shading bucket b, [RT_COUNTER_HEAD] */
-#define RT_COUNTER_HEAD 9u    /* queue head of the persistent tree kernel */
+#define RT_COUNTER_STRIDE 16u /* per iteration: [0] live paths entering it, [1+b] hits queued for shading bucket b */
 
 // ---- device structures ------------------------------------------------------------------------------------
 // Path state, one record per path, each record one 64-byte line: once the live queue has been compacted the slots a
@@ -261,19 +259,24 @@ __global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtCameraDev cam, PassInfo p
 // Persistent waves. Once rays are incoherent the number of box tests differs by an order of magnitude from
 // lane to lane, and box tests and leaf tests interleave differently in every lane. So:
 //  * a lane that has finished its ray does not wait for the slowest one: when `refill_min` lanes of a wave
-//    are out of work they take the next rays of the queue (one atomic on the queue head per refill);
+//    are out of work they take the next rays of the queue. The queue is dealt to the workgroups in pieces
+//    (piece c belongs to workgroup c mod gridDim) and the waves of a workgroup draw from its pieces through a
+//    counter in LDS: a counter in global memory takes ~90 atomics per microsecond chip-wide, which at one
+//    atomic per 64 rays would cap the kernel at 6 G rays/s and dominate small launches;
 //  * box tests run for all lanes that hold a node until `leaf_min` lanes wait at a leaf; then those
 //    leaves are tested together.
 // Which lane traces which ray, and when, has no effect on results.
 __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
                                                                uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_min,
                                                                uint32_t n_cached) {
-    extern __shared__ uint4 lds_tree[]; // stack_cap * blockDim.x words of stack, then n_cached node records
+    extern __shared__ uint4 lds_tree[]; // stack_cap * blockDim.x words of stack, n_cached node records, the queue counter
     const uint32_t* live = it == 0u ? nullptr : qs.live[it & 1u];
     uint32_t* ctr = qs.counters + it * RT_COUNTER_STRIDE;
     const uint32_t n = ctr[0];
     if (n == 0u) return;
-    uint32_t* head = ctr + RT_COUNTER_HEAD;
+    // queue positions handed out in this workgroup so far: the 16 bytes behind the node records
+    uint32_t& blk_taken = *(uint32_t*)(lds_tree + (size_t)stack_cap * blockDim.x / 4u + (size_t)n_cached * 4u);
+    if (threadIdx.x == 0u) blk_taken = 0u;
     LdsStack st;
     st.base = (uint32_t*)lds_tree + threadIdx.x;
     st.cap = stack_cap;
@@ -297,28 +300,27 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
     uint32_t slot = 0u;
     bool active = false;    // tracing a ray
     bool exhausted = false; // wave-uniform: the queue has no more rays
-    // the wave draws queue indices from a private chunk and takes a new chunk (one atomic) when it runs out
-    // (chunk size: large enough to keep atomics rare, small enough that every wave of the grid gets several)
-    uint32_t chunk_next = 0u, chunk_end = 0u;
-    const uint32_t chunk = max(64u, min((uint32_t)RT_TREE_CHUNK, (n / (gridDim.x * (blockDim.x / 64u) * 8u)) & ~63u));
+    // pieces of 2^shift queue indices, about 8 per workgroup, between 256 and 4096 indices each
+    uint32_t shift = 8u;
+    while (shift < 12u && ((n / gridDim.x) >> (shift + 3u)) > 0u) ++shift;
+    // position v in this workgroup's share of the queue -> queue index (monotonic in v)
+    auto index_of = [&](uint32_t v) -> unsigned long long {
+        const unsigned long long piece = (unsigned long long)(v >> shift) * gridDim.x + blockIdx.x;
+        return (piece << shift) + (v & ((1u << shift) - 1u));
+    };
 #pragma unroll 1
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         if (n_idle == 64u && exhausted) break;
         if (n_idle >= refill_min && !exhausted) { // hand idle lanes the next rays
-            if (chunk_next >= chunk_end) {
-                uint32_t c = 0u;
-                if (lane == 0u) c = atomicAdd(head, chunk);
-                chunk_next = __shfl(c, 0);
-                chunk_end = chunk_next + chunk;
-            }
-            const uint32_t base = chunk_next;
-            chunk_next = min(chunk_next + n_idle, chunk_end); // lanes past the end of the chunk stay idle until the next refill
+            uint32_t v0 = 0u;
+            if (lane == 0u) v0 = atomicAdd(&blk_taken, n_idle);
+            v0 = __shfl(v0, 0);
             if (!active) {
-                const uint32_t i = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                if (i < n && i < chunk_end) {
-                    slot = live ? live[i] : i;
+                const unsigned long long i = index_of(v0 + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)));
+                if (i < n) {
+                    slot = live ? live[i] : (uint32_t)i;
                     s.r = load_ray(pb, slot);
                     s.best.t = RT_INF; s.best.ref = RT_REF_NONE; s.best.aux = 0u;
                     // the world entries every ray is tested against, by the lanes that just took a ray, in lock step
@@ -333,7 +335,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
                     active = true;
                 }
             }
-            if (chunk_next >= n) exhausted = true;
+            if (index_of(v0 + n_idle) >= n) exhausted = true; // whoever draws next would find nothing
             if (__ballot(active) == 0ull && exhausted) break;
         }
         // ---- box tests: every lane that holds a node steps ----
@@ -905,9 +907,9 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
     // Persistent waves, one workgroup per CU: its LDS holds the traversal stacks and, in what is left, the first
     // records of the node array (the compiler numbers nodes breadth-first, so these are the ones nearest the root).
     const size_t lds_stack_bytes = (size_t)stack_cap * RT_TREE_BLOCK * sizeof(uint32_t);
-    if (lds_stack_bytes > ctx->lds_per_block) return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "render: traversal stacks exceed the LDS of a workgroup");
-    const uint32_t n_cached = (uint32_t)std::min<size_t>(sc->hdr.nodes.count, (ctx->lds_per_block - lds_stack_bytes) / sizeof(RtNode));
-    const size_t lds = lds_stack_bytes + (size_t)n_cached * sizeof(RtNode);
+    if (lds_stack_bytes + 16 > ctx->lds_per_block) return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "render: traversal stacks exceed the LDS of a workgroup");
+    const uint32_t n_cached = (uint32_t)std::min<size_t>(sc->hdr.nodes.count, (ctx->lds_per_block - lds_stack_bytes - 16) / sizeof(RtNode));
+    const size_t lds = lds_stack_bytes + (size_t)n_cached * sizeof(RtNode) + 16;
     if (lds > 65536)
         RT_HIP(hipFuncSetAttribute((const void*)k_extend_tree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size of k_extend_tree");
     const uint32_t extend_blocks_per_cu = 1u;
