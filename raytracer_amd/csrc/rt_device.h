@@ -296,6 +296,11 @@ struct RtBest {
     double t;
     uint32_t ref, aux;
 };
+// A host build that wants to know how much work a ray causes defines RT_VISIT(kind) before including this header
+// (kinds: 0 = a node's two box tests, 1 + RtRefType = a test of that kind of object).
+#ifndef RT_VISIT
+#define RT_VISIT(kind) ((void)0)
+#endif
 
 // One non-node reference against the ray of its frame. Returns true if it became the closest hit.
 template <class XiFn>
@@ -303,6 +308,7 @@ RT_HD void rt_test_leaf(const DScene& sc, uint32_t ref, const Ray& r, double t_m
                         bool skip_media) {
     const uint32_t idx = RT_REF_INDEX(ref);
     double t;
+    RT_VISIT(1u + RT_REF_TYPE(ref));
     switch (RT_REF_TYPE(ref)) {
     case RT_REF_SPHERE: {
         const RtSphere s = sc.spheres[idx];
@@ -363,6 +369,7 @@ struct GlobalNodes {
 template <class Stack, class Nodes>
 RT_HD void rt_trav_node_step(const Nodes& nodes, RtTrav& s, Stack& st, double t_min) {
     const RtNode n = nodes.load(RT_REF_INDEX(s.cur));
+    RT_VISIT(0u);
     double e0, e1;
     const bool h0 = rt_aabb_hit(n.lo0, n.hi0, s.r, s.slab, t_min, s.best.t, e0);
     const bool h1 = rt_aabb_hit(n.lo1, n.hi1, s.r, s.slab, t_min, s.best.t, e1);

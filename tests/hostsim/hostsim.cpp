@@ -2,6 +2,11 @@
 // straight from a compiled scene blob. It exists so that the blob layout, the traversal, the hit
 // reconstruction and the materials can be checked against the oracle in a container without a GPU, and under
 // host sanitizers. It is never loaded by the product and is not a fallback: the product has no CPU path.
+#include <stdint.h>
+// work counters of the traversal, per bounce: [bounce][0] node visits, [bounce][1 + RtRefType] object tests
+static thread_local uint64_t (*g_visits)[12] = nullptr;
+static thread_local uint32_t g_bounce = 0;
+#define RT_VISIT(kind) do { if (g_visits) ++g_visits[g_bounce][(kind)]; } while (0)
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -142,6 +147,8 @@ static V3 sample_radiance(const DScene& sc, const RtCameraDev& cd, const rt_para
         PhiloxXi xi;
         xi.s = smp;
         if (segments) ++*segments;
+        g_bounce = it;
+        if (g_visits) ++g_visits[it][11];
         HeldRay held;
         held.r = r;
         const RtHitLite h = rt_extend(sc, held, 0.001, RT_INF, st, xi, false);
@@ -196,6 +203,24 @@ int hs_sample_radiance(const void* blob, size_t nbytes, const rt_camera* cam, co
     if (rc != RT_OK) return rc;
     const V3 c = sample_radiance(sc, cd, p, x, y, sample, nullptr);
     rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
+    return RT_OK;
+}
+
+// Work per bounce over a whole render: visits[bounce][0] node visits, [1 + RtRefType] object tests, [11] segments.
+int hs_visit_stats(const void* blob, size_t nbytes, const rt_camera* cam, const rt_params* p, uint32_t spp, uint64_t* visits /* max_depth x 12 */) {
+    DScene sc;
+    RtBlobHeader h;
+    if (!view_of(blob, nbytes, sc, h)) return RT_ERR_INVALID;
+    sc.compat = p->compat;
+    RtCameraDev cd;
+    int rc = rt_camera_derive(cam, &cd);
+    if (rc != RT_OK) return rc;
+    memset(visits, 0, sizeof(uint64_t) * 12 * p->max_depth);
+    g_visits = (uint64_t (*)[12])visits;
+    for (uint32_t y = 0; y < p->height; ++y)
+        for (uint32_t x = 0; x < p->width; ++x)
+            for (uint32_t s = 0; s < spp; ++s) sample_radiance(sc, cd, p, x, y, s, nullptr);
+    g_visits = nullptr;
     return RT_OK;
 }
 
