@@ -74,21 +74,20 @@ struct LdsStack {
 // 256 per wave and node, which is what bounds traversal when the nodes come from global memory. The LDS serves the
 // same reads at its full width. The 16-byte pieces of a record are stored rotated by the record's index so that the
 // lanes of one read spread over all banks.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) u32x4* LdsU4; // typed as LDS so that reads are ds_read, not flat loads
 struct CachedNodes {
-    const uint4* lds;
+    LdsU4 lds;
     uint32_t n_cached;
     const RtNode* global;
     __device__ static uint32_t place(uint32_t index, uint32_t piece) { return index * 4u + (piece ^ ((index >> 2) & 3u)); }
     __device__ RtNode load(uint32_t index) const {
-        uint4 a, b, c;
-        uint2 d;
+        u32x4 a, b, c, d; // (d as a full 16-byte read too: a narrower one gets merged with the other branch's into a flat load)
         if (index < n_cached) {
-            a = lds[place(index, 0u)]; b = lds[place(index, 1u)]; c = lds[place(index, 2u)];
-            d = *(const uint2*)(lds + place(index, 3u));
+            a = lds[place(index, 0u)]; b = lds[place(index, 1u)]; c = lds[place(index, 2u)]; d = lds[place(index, 3u)];
         } else {
-            const uint4* g = (const uint4*)(global + index);
-            a = g[0]; b = g[1]; c = g[2];
-            d = *(const uint2*)(g + 3);
+            const u32x4* g = (const u32x4*)(global + index);
+            a = g[0]; b = g[1]; c = g[2]; d = g[3];
         }
         RtNode n;
         n.lo0[0] = __uint_as_float(a.x); n.lo0[1] = __uint_as_float(a.y); n.lo0[2] = __uint_as_float(a.z);
@@ -288,7 +287,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
         uint4* cache = lds_tree + (size_t)stack_cap * blockDim.x / 4u;
         const uint4* src = (const uint4*)sc.nodes;
         for (uint32_t i = threadIdx.x; i < n_cached * 4u; i += blockDim.x) cache[CachedNodes::place(i >> 2, i & 3u)] = src[i];
-        nodes.lds = cache;
+        nodes.lds = (LdsU4)cache;
         nodes.n_cached = n_cached;
         nodes.global = sc.nodes;
         __syncthreads();
