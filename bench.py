@@ -26,12 +26,31 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X vector FP64 spec peak
-# Algorithmic HBM bytes k_extend_tree moves per ray segment in this layout: live-queue index read (4) + ray 7 x f64
-# read (56) + seed hit record read (16) + hit record write (16).
-EXTEND_BYTES_PER_SEGMENT = 92
-# Whole-path compulsory path-state traffic per segment, f64 layout: flat pass 4 + 56 + 16; tree pass 92; bin
-# 4 + 16 + 4; shade reads 4 + 56 + 16 + 24 (throughput) and writes 48 (next ray) + 24 + 4.
-PATH_BYTES_PER_SEGMENT = 368
+# Algorithmic HBM bytes k_extend_tree moves per ray segment in this layout: live-queue index read (4) + ray record
+# read (7 x f64 = 56) + hit record write (16).
+EXTEND_BYTES_PER_SEGMENT = 76
+# Whole-path compulsory path-state traffic per segment, f64 layout: extend 76; bin 4 + 16 + 4; shade reads
+# 4 + 56 + 16 + 24 (throughput) and writes 56 (next ray) + 24 + 4.
+PATH_BYTES_PER_SEGMENT = 284
+# Work per segment under the REFERENCE's traversal (always both children, no ordering), counted by the oracle and
+# committed as tests/golden/visits.json: flops = 27 per box test (3 divides, 6 sub, 6 mul, 6 select, 6 compare) + 25 per
+# sphere + 12 per rect + 60 for the scatter; scene bytes = 32 per box test and sphere, 48 per rect.
+FLOPS = dict(node_tests=27, sphere_tests=25, moving_sphere_tests=30, rect_tests=12, medium_tests=60)
+SCENE_BYTES = dict(node_tests=32, sphere_tests=32, moving_sphere_tests=80, rect_tests=48, medium_tests=40)
+SHADE_FLOPS = 60
+
+
+def reference_work_per_segment(scene):
+    path = os.path.join(ROOT, "tests", "golden", "visits.json")
+    if not os.path.exists(path):
+        return None
+    v = json.load(open(path)).get(scene)
+    if not v:
+        return None
+    seg = float(v["ray_segments"])
+    per = {k: v[k] / seg for k in FLOPS}
+    return {"per_segment": per, "flops": SHADE_FLOPS + sum(FLOPS[k] * per[k] for k in FLOPS),
+            "scene_bytes": sum(SCENE_BYTES[k] * per[k] for k in FLOPS)}
 
 
 def cpu_baseline(desc, info, seed, target_seconds):
@@ -141,6 +160,8 @@ def main():
         seg_per_launch = stats.extend_segments / max(1, stats.extend_launches)
         avg_ms = stats.extend_ms / max(1, stats.extend_launches)
         achieved = EXTEND_BYTES_PER_SEGMENT * seg_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        ref_work = reference_work_per_segment(args.scene)
+        rate = segments / elapsed / world  # per GPU
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "extend_hbm_traffic.json")
         if os.path.exists(pmc_path):
@@ -165,7 +186,11 @@ def main():
                 "note": "cache-resident scene: the kernel is bound by f64 VALU issue and latency under divergence, "
                         "not by HBM; the HBM figure is the compulsory path-state traffic only",
             },
-            "path_hbm_frac": PATH_BYTES_PER_SEGMENT * (segments / world) / elapsed / 1e9 / HBM_PEAK_GBS,
+            "path_hbm_frac": PATH_BYTES_PER_SEGMENT * rate / 1e9 / HBM_PEAK_GBS,
+            # the same rate priced in the reference traversal's arithmetic and scene reads (the GPU path does less of both)
+            "reference_work": None if ref_work is None else dict(
+                ref_work, fp64_vector_frac=ref_work["flops"] * rate / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                scene_read_gbs=ref_work["scene_bytes"] * rate / 1e9),
             "kernel_ms": {"raygen": stats.raygen_ms, "extend_flat": stats.flat_ms, "extend_tree": stats.extend_ms, "bin": stats.bin_ms,
                           "accumulate": stats.accumulate_ms,
                           "shade_lambertian": stats.shade_ms[0], "shade_metal": stats.shade_ms[1],

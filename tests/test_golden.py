@@ -53,3 +53,15 @@ def test_gpu_reproduces_golden(gpu_ctx, name):
     img = gpu_ctx.render(scene, info.camera, p, 4)
     assert (util.rel_err(img, g["image"]) > 1e-9).mean() <= 0.01
     scene.close()
+
+
+def test_oracle_reproduces_the_committed_visit_counts():
+    import json
+    want = json.load(open(os.path.join(GOLDEN, "visits.json")))
+    assert set(want) == set(util.SCENES)
+    for name in ("final_scene", "cornell_box"):
+        _, info, blob, desc = util.build_scene(name)
+        got = util.oracle_visits(ck.OracleScene(desc, share_bvh_axes=True), info)
+        # media draw log(): an ulp between libms can end a path one segment earlier, so counts agree closely, not exactly
+        for k, v in want[name].items():
+            assert abs(got[k] - v) <= 0.002 * max(v, 1), (name, k, got[k], v)

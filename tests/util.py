@@ -104,3 +104,16 @@ def ids_without_uv(description):
 
 def luminance(rgb):
     return 0.2126 * rgb[..., 0] + 0.7152 * rgb[..., 1] + 0.0722 * rgb[..., 2]
+
+
+VISITS_SHAPE = dict(width=96, height=96, spp=8)
+
+
+def oracle_visits(osc, info):
+    """Calls the oracle makes per render of VISITS_SHAPE: box tests (one per BvhNode::hit, bvh.rs:113) and primitive
+    hit() calls by kind, with the segment count they are spread over. Deterministic in the seeds."""
+    p = api.params_from_info(info, seed=RENDER_SEED, width=VISITS_SHAPE["width"], height=VISITS_SHAPE["height"])
+    _, st = osc.render(info.camera, p, VISITS_SHAPE["spp"], threads=4)
+    return dict(VISITS_SHAPE, camera_samples=int(st.camera_samples), ray_segments=int(st.ray_segments), node_tests=int(st.node_tests),
+                sphere_tests=int(st.sphere_tests), moving_sphere_tests=int(st.moving_sphere_tests), rect_tests=int(st.rect_tests),
+                medium_tests=int(st.medium_tests))

@@ -15,8 +15,11 @@ import checkers as ck  # noqa: E402
 import util  # noqa: E402
 from raytracer_amd import api  # noqa: E402
 
+import json  # noqa: E402
+
 out_dir = os.path.join(ROOT, "tests", "golden")
 os.makedirs(out_dir, exist_ok=True)
+visits = {}
 for name in util.SCENES:
     _, info, blob, desc = util.build_scene(name)
     osc = ck.OracleScene(desc, share_bvh_axes=True)
@@ -31,3 +34,7 @@ for name in util.SCENES:
     np.savez_compressed(os.path.join(out_dir, name + ".npz"), rays=rays, xi=xi, hits=hits, image=img,
                         segments=np.uint64(st.ray_segments))
     print(name, len(rays), "rays,", int((hits["prim_id"] != 0xFFFFFFFF).sum()), "hits, image mean %.6f" % img.mean())
+    # work per path segment under the reference's traversal (every BvhNode::hit, every primitive hit() call), which
+    # is what the roofline's scene-traffic and flop figures are stated in
+    visits[name] = util.oracle_visits(osc, info)
+json.dump(visits, open(os.path.join(out_dir, "visits.json"), "w"), indent=1, sort_keys=True)
