@@ -5,16 +5,18 @@
 //
 //   k_raygen                 slot = local_pixel * S + s  ->  primary ray, throughput 1, radiance 0
 //   per bounce it = 0 .. max_depth-1
-//     k_extend               closest hit of every live path (LDS stack traversal); misses are finished in
-//                            place; hits are binned by material type with wave ballots into 5 queues
-//     k_shade<material> x5   rebuild the hit record, emitted + scatter, write the next ray, and compact
-//                            surviving paths into the next iteration's queue (ballot + one atomic per wave)
+//     k_extend_tree          closest hit of every live path: persistent waves, one 1024-thread workgroup per CU,
+//                            per-lane stacks and the top of the node array in LDS
+//     k_bin                  misses take the background and end; hits are queued by what shading them runs
+//                            (material type x plain-colour or computed texture): 8 queues, one block-wide append
+//     k_shade<bucket>        rebuild the hit record, emitted + scatter, write the next ray, and compact the
+//                            surviving paths into the next iteration's queue (one atomic per workgroup)
 //   k_accumulate             per pixel, add its S sample radiances in sample order to the f64 sum buffer
 //
-// Path state is structure-of-arrays f64 in HBM. All queue lengths live in a device counter table that the
-// kernels read themselves, so the host never waits between launches inside a pass.
-// Random numbers are Philox keyed on (pixel, sample, bounce): results do not depend on how pixels are
-// split over GPUs or on scheduling.
+// Path state is one 64-byte record per path and array (ray; throughput + radiance) plus a 16-byte hit record.
+// All queue lengths live in a device counter table that the kernels read themselves, so the host never waits
+// between launches inside a pass. Random numbers are Philox keyed on (pixel, sample, bounce): results do not
+// depend on how pixels are split over GPUs or on scheduling.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
