@@ -102,7 +102,7 @@ def main():
     desc = None
     if rank == 0:
         b = api.Builder(seed=scene_seed)
-        b.register_reference_textures()
+        b.register_reference_textures(tuple(api.TEXTURE_FILES) if args.scene == "my_scene" else ("earthmap.jpg",))
         info = b.named_scene(args.scene, scene_seed)
         blob = b.compile(info.world)
         desc = b.describe(info.world)
@@ -111,7 +111,7 @@ def main():
         buf = rdist.broadcast_blob(blob if rank == 0 else None, device)
         if rank != 0:
             b = api.Builder(seed=scene_seed)
-            b.register_reference_textures()
+            b.register_reference_textures(tuple(api.TEXTURE_FILES) if args.scene == "my_scene" else ("earthmap.jpg",))
             info = b.named_scene(args.scene, scene_seed)
         scene = ctx.upload_from_device(buf.data_ptr(), buf.numel())
     else:
@@ -171,8 +171,9 @@ def main():
             "samples_per_sec": samples / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Book-2 final scene (final_scene, main.rs:576-688), 800x800, max depth 50, "
-                                   "%d spp per step (%d per GPU), scene seed 0x5EED0001, render seed 0x5EED0002" % (spp_step, args.spp),
+            "config": {"workload": "%s, %dx%d, max depth %d, %d spp per step (%d per GPU), scene seed 0x5EED0001, render seed 0x5EED0002" %
+                                   ("Book-2 final scene (final_scene, main.rs:576-688)" if args.scene == "final_scene" else "scene " + args.scene,
+                                    W, H, info.max_depth, spp_step, args.spp),
                        "scene": args.scene, "width": W, "height": H, "spp_per_step": spp_step, "max_depth": info.max_depth,
                        "tile": rdist.DEFAULT_TILE, "sharding": "tiles round-robin over %d rank(s)" % world},
             "rays_per_sample": segments / samples,

@@ -8,7 +8,7 @@ RENDER_SEED = 0x5EED0002
 # name -> extra argument n
 SCENES = {
     "final_scene": 0, "cornell_box": 0, "cornell_smoke": 0, "random_scene": 0, "two_spheres": 0,
-    "two_perlin_spheres": 0, "earth": 0, "simple_light": 0, "stress_volume": 0, "spheres_grid": 4096,
+    "two_perlin_spheres": 0, "earth": 0, "simple_light": 0, "stress_volume": 0, "spheres_grid": 4096, "my_scene": 0,
 }
 
 

@@ -16,7 +16,7 @@ ap.add_argument("--width", type=int, default=0)
 ap.add_argument("--height", type=int, default=0)
 a = ap.parse_args()
 b = api.Builder()
-b.register_reference_textures()
+b.register_reference_textures(tuple(api.TEXTURE_FILES) if a.scene == "my_scene" else ("earthmap.jpg",))
 info = b.named_scene(a.scene, n=a.n)
 ctx = api.Context(0)
 sc = ctx.upload(b.compile(info.world))
