@@ -36,14 +36,18 @@
 #define RT_COUNTER_STRIDE 16u /* per iteration: [0] live paths entering it, [1+b] hits queued for shading bucket b */
 
 // ---- device structures ------------------------------------------------------------------------------------
-// Path state, one record per path, each record one 64-byte line: once the live queue has been compacted the slots a
-// wave touches are scattered, and a scattered 8-byte access costs a whole line anyway.
-struct PathRay { double ox, oy, oz, dx, dy, dz, tm, pad; };            // current ray (ray.rs:5-9)
-struct PathAcc { double tr, tg, tb, rr, rg, rb, pad0, pad1; };         // throughput (product of attenuations, main.rs:70) and radiance
+// Path state. The paths alive at a bounce are DENSE: path number i of the bounce owns record i of the bounce's ray,
+// throughput and hit arrays, and a shade kernel writes a surviving path's next ray and throughput to the record the
+// path gets in the next bounce's arrays (two sets, alternating). So every kernel streams through contiguous records
+// and nothing is read through an index; what ties a record to its pixel is the slot number it carries. Only the
+// radiance array is indexed by slot, and it is written once per path, when the path ends.
+struct PathRay { double ox, oy, oz, dx, dy, dz, tm; uint32_t slot, pad; }; // current ray (ray.rs:5-9) + slot = local_pixel * S + sample
+struct PathThr { double r, g, b, pad; };                                  // product of the attenuations so far (main.rs:70)
 struct PathBufs {
-    PathRay* ray;
-    PathAcc* acc;
-    RtHitLite* hit;
+    PathRay* ray[2];  // [it & 1]: rays entering bounce it
+    PathThr* thr[2];
+    double* rad;      // 3 per slot: what the path adds to its pixel
+    RtHitLite* hit;   // per path of the current bounce
 };
 struct PassInfo {
     const uint32_t* pixmap; // local pixel -> global pixel index y*width + x
@@ -52,8 +56,7 @@ struct PassInfo {
     uint64_t seed;
 };
 struct QueueSet {
-    uint32_t* live[2];          // slot ids entering iteration it: live[it & 1]
-    uint32_t* bucket;           // RT_BUCKET_COUNT queues of bucket_cap entries each, one per shading bucket
+    uint32_t* bucket;           // RT_BUCKET_COUNT queues of bucket_cap path numbers each, one per shading bucket
     size_t bucket_cap;
     uint32_t* counters;         // (max_depth + 2) * RT_COUNTER_STRIDE
     uint32_t* error_flag;       // bit 0: traversal stack overflow
@@ -113,36 +116,15 @@ struct ArrayXi { // injected uniforms for rt_trace_first_hit
     __device__ double operator()(uint32_t medium_index) const { return row[medium_index]; }
 };
 
-// Appends `slot` of every lane with `take` set to queue `q`; one atomic per wave. All lanes of the wave call it.
-__device__ inline void wave_append(bool take, uint32_t slot, uint32_t* q, uint32_t* counter) {
-    const unsigned long long mask = __ballot(take);
-    if (mask == 0ull) return;
-    const uint32_t lane = __lane_id();
-    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-    uint32_t base = 0u;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, (int)leader);
-    if (take) q[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
-}
-
-// The same for a whole workgroup and R items per thread: ONE atomic per call (a single counter word takes only
-// ~90 atomics per microsecond chip-wide, so per-wave appends of millions of waves would serialise on it).
-// `scratch` = RT_BLOCK/64 + 1 words of LDS. Every thread of the block must call it.
-template <int R>
-__device__ inline void block_append(const bool (&take)[R], const uint32_t (&slot)[R], uint32_t* q, uint32_t* counter,
-                                    uint32_t* scratch) {
+// Hands every thread with `take` set a distinct position counted from *counter: ONE atomic per workgroup (a single
+// counter word takes only ~90 atomics per microsecond chip-wide, so per-wave appends of millions of waves would
+// serialise on it). `scratch` = RT_BLOCK/64 + 1 words of LDS. Every thread of the block must call it.
+__device__ inline uint32_t block_reserve(bool take, uint32_t* counter, uint32_t* scratch) {
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
-    uint32_t rank[R];
-    uint32_t mine = 0u;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const unsigned long long mask = __ballot(take[r]);
-        rank[r] = mine + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        mine += (uint32_t)__popcll(mask);
-    }
-    // `mine` is now the wave's total (identical in every lane)
+    const unsigned long long mask = __ballot(take);
+    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     __syncthreads();
-    if (lane == 0u) scratch[wave] = mine;
+    if (lane == 0u) scratch[wave] = (uint32_t)__popcll(mask);
     __syncthreads();
     if (threadIdx.x == 0u) {
         uint32_t total = 0u;
@@ -150,10 +132,7 @@ __device__ inline void block_append(const bool (&take)[R], const uint32_t (&slot
         scratch[RT_BLOCK / 64u] = total ? atomicAdd(counter, total) : 0u;
     }
     __syncthreads();
-    const uint32_t base = scratch[RT_BLOCK / 64u] + scratch[wave];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (take[r]) q[base + rank[r]] = slot[r];
+    return scratch[RT_BLOCK / 64u] + scratch[wave] + rank;
 }
 
 // R items per thread, each for one of Q queues (which[r] >= Q: none): one atomic per queue per call, two barriers.
@@ -194,19 +173,19 @@ __device__ inline void block_append_multi(const uint32_t (&which)[R], const uint
         if (which[r] < (uint32_t)Q) qbase[(size_t)which[r] * qcap + lds[which[r] * W + wave] + rank[r]] = slot[r];
 }
 
-__device__ inline Ray load_ray(const PathBufs& pb, uint32_t slot) {
+__device__ inline Ray load_ray(const PathRay* rec, uint32_t& slot) {
     Ray r;
-    const double2* q = (const double2*)(pb.ray + slot);
+    const double2* q = (const double2*)rec;
     const double2 a = q[0], b = q[1], c = q[2], d = q[3];
     r.o = v3(a.x, a.y, b.x);
     r.d = v3(b.y, c.x, c.y);
     r.tm = d.x;
+    slot = (uint32_t)__double_as_longlong(d.y);
     return r;
 }
-struct SlotRay { // the world-space ray of a path, re-read from the path buffers on demand
-    const PathBufs* pb;
-    uint32_t slot;
-    __device__ Ray operator()() const { return load_ray(*pb, slot); }
+struct SlotRay { // the world-space ray of a path, re-read from its record on demand
+    const PathRay* rec;
+    __device__ Ray operator()() const { uint32_t slot; return load_ray(rec, slot); }
 };
 struct HeldRay { // the world-space ray, still held in registers
     const Ray* r;
@@ -220,12 +199,12 @@ struct QueryRay {
         return r;
     }
 };
-__device__ inline void store_ray(const PathBufs& pb, uint32_t slot, const Ray& r) {
-    double2* q = (double2*)(pb.ray + slot);
+__device__ inline void store_ray(PathRay* rec, const Ray& r, uint32_t slot) {
+    double2* q = (double2*)rec;
     q[0] = make_double2(r.o.x, r.o.y);
     q[1] = make_double2(r.o.z, r.d.x);
     q[2] = make_double2(r.d.y, r.d.z);
-    q[3] = make_double2(r.tm, 0.0);
+    q[3] = make_double2(r.tm, __longlong_as_double((long long)slot));
 }
 __device__ inline Sampler slot_sampler(const PassInfo& pi, uint32_t slot, uint32_t bounce) {
     const uint32_t lp = slot / pi.S, s = slot - lp * pi.S;
@@ -245,10 +224,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtCameraDev cam, PassInfo p
         const uint32_t y = pixel / pi.width, x = pixel - y * pi.width;
         const Sampler smp = sampler_make(pixel, pi.sample_offset + s, 0u, pi.seed);
         const Ray r = rt_primary_ray(cam, x, y, pi.width, pi.height, smp, pi.compat);
-        store_ray(pb, slot, r);
-        PathAcc acc;
-        acc.tr = 1.0; acc.tg = 1.0; acc.tb = 1.0; acc.rr = 0.0; acc.rg = 0.0; acc.rb = 0.0; acc.pad0 = 0.0; acc.pad1 = 0.0;
-        pb.acc[slot] = acc;
+        store_ray(pb.ray[0] + slot, r, slot); // before the first bounce path number = slot
+        PathThr one;
+        one.r = 1.0; one.g = 1.0; one.b = 1.0; one.pad = 0.0;
+        pb.thr[0][slot] = one;
+        pb.rad[3u * (size_t)slot] = 0.0; pb.rad[3u * (size_t)slot + 1u] = 0.0; pb.rad[3u * (size_t)slot + 2u] = 0.0;
     }
 }
 
@@ -271,7 +251,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
                                                                uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_min,
                                                                uint32_t n_cached) {
     extern __shared__ uint4 lds_tree[]; // stack_cap * blockDim.x words of stack, n_cached node records, the queue counter
-    const uint32_t* live = it == 0u ? nullptr : qs.live[it & 1u];
+    const PathRay* rays = pb.ray[it & 1u];
     uint32_t* ctr = qs.counters + it * RT_COUNTER_STRIDE;
     const uint32_t n = ctr[0];
     if (n == 0u) return;
@@ -298,7 +278,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
     RtTrav s;
     s.cur = RT_REF_NONE;
     s.best.t = RT_INF; s.best.ref = RT_REF_NONE; s.best.aux = 0u;
-    uint32_t slot = 0u;
+    uint32_t slot = 0u, path = 0u;
     bool active = false;    // tracing a ray
     bool exhausted = false; // wave-uniform: the queue has no more rays
     // pieces of 2^shift queue indices, about 8 per workgroup, between 256 and 4096 indices each
@@ -321,8 +301,8 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             if (!active) {
                 const unsigned long long i = index_of(v0 + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)));
                 if (i < n) {
-                    slot = live ? live[i] : (uint32_t)i;
-                    s.r = load_ray(pb, slot);
+                    path = (uint32_t)i;
+                    s.r = load_ray(rays + path, slot);
                     s.best.t = RT_INF; s.best.ref = RT_REF_NONE; s.best.aux = 0u;
                     // the world entries every ray is tested against, by the lanes that just took a ray, in lock step
                     HeldRay held;
@@ -350,7 +330,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
         // ---- one non-node reference for every lane that holds one ----
         if (active && s.cur != RT_REF_NONE && RT_REF_TYPE(s.cur) != RT_REF_NODE) {
             SlotRay ray_of;
-            ray_of.pb = &pb; ray_of.slot = slot;
+            ray_of.rec = rays + path;
             PhiloxXi xi;
             xi.pi = &pi; xi.slot = slot; xi.bounce = it;
             rt_trav_visit(sc, s, st, 0.001, xi, false, ray_of);
@@ -358,7 +338,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
         if (active && s.cur == RT_REF_NONE) { // finished: publish the closest hit
             RtHitLite h;
             h.t = s.best.t; h.ref = s.best.ref; h.aux = s.best.aux;
-            pb.hit[slot] = h;
+            pb.hit[path] = h;
             active = false;
         }
     }
@@ -366,27 +346,30 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
 
 __global__ void __launch_bounds__(RT_BLOCK) k_bin(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it) {
     __shared__ uint32_t lds[RT_BUCKET_COUNT * (RT_BLOCK / 64)];
-    const uint32_t* live = it == 0u ? nullptr : qs.live[it & 1u];
+    const PathRay* rays = pb.ray[it & 1u];
+    const PathThr* thr = pb.thr[it & 1u];
     uint32_t* ctr = qs.counters + it * RT_COUNTER_STRIDE;
     const uint32_t n = ctr[0];
     const uint32_t per_block = RT_BLOCK * RT_BIN_PER_THREAD;
     // whole blocks iterate together: the append synchronises the block
     for (uint32_t base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
-        uint32_t slot[RT_BIN_PER_THREAD], bucket[RT_BIN_PER_THREAD];
+        uint32_t path[RT_BIN_PER_THREAD], bucket[RT_BIN_PER_THREAD];
 #pragma unroll
         for (int r = 0; r < RT_BIN_PER_THREAD; ++r) {
             const uint32_t i = base + (uint32_t)r * RT_BLOCK + threadIdx.x;
-            slot[r] = 0u;
+            path[r] = i;
             bucket[r] = 0xFFFFFFFFu;
             if (i < n) {
-                slot[r] = live ? live[i] : i;
-                const RtHitLite h = pb.hit[slot[r]];
-                if (h.ref == RT_REF_NONE) { // main.rs:56-58: return background
-                    const V3 bg = rt_background(pi.bg, pi.bg_mode, load_ray(pb, slot[r]));
-                    PathAcc* acc = pb.acc + slot[r];
-                    acc->rr += acc->tr * bg.x;
-                    acc->rg += acc->tg * bg.y;
-                    acc->rb += acc->tb * bg.z;
+                const RtHitLite h = pb.hit[i];
+                if (h.ref == RT_REF_NONE) { // main.rs:56-58: return background; the path ends here
+                    uint32_t slot;
+                    const Ray ray = load_ray(rays + i, slot);
+                    const V3 bg = rt_background(pi.bg, pi.bg_mode, ray);
+                    const PathThr t = thr[i];
+                    double* rad = pb.rad + 3u * (size_t)slot;
+                    rad[0] += t.r * bg.x;
+                    rad[1] += t.g * bg.y;
+                    rad[2] += t.b * bg.z;
                 } else {
                     uint32_t m;
                     const uint32_t ty = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
@@ -401,7 +384,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_bin(DScene sc, PassInfo pi, PathBu
                 }
             }
         }
-        block_append_multi<RT_BIN_PER_THREAD, RT_BUCKET_COUNT>(bucket, slot, qs.bucket, qs.bucket_cap, ctr + 1u, lds);
+        block_append_multi<RT_BIN_PER_THREAD, RT_BUCKET_COUNT>(bucket, path, qs.bucket, qs.bucket_cap, ctr + 1u, lds);
         __syncthreads();
     }
 }
@@ -414,17 +397,25 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
     __shared__ uint32_t scratch[RT_BLOCK / 64 + 1];
     const uint32_t* bucket = qs.bucket + (size_t)BUCKET * qs.bucket_cap;
     const uint32_t n = qs.counters[it * RT_COUNTER_STRIDE + 1u + BUCKET];
-    uint32_t* next = qs.live[(it + 1u) & 1u];
+    const PathRay* rays = pb.ray[it & 1u];
+    const PathThr* thr = pb.thr[it & 1u];
+    PathRay* next_rays = pb.ray[(it + 1u) & 1u];
+    PathThr* next_thr = pb.thr[(it + 1u) & 1u];
     uint32_t* next_counter = qs.counters + (it + 1u) * RT_COUNTER_STRIDE;
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < n;
         uint32_t slot = 0u;
         bool alive = false;
+        Ray scattered;
+        PathThr t;
+        scattered.o = v3(0.0, 0.0, 0.0); scattered.d = v3(0.0, 0.0, 0.0); scattered.tm = 0.0;
+        t.r = 0.0; t.g = 0.0; t.b = 0.0; t.pad = 0.0;
         if (active) {
-            slot = bucket[i];
-            const Ray r = load_ray(pb, slot);
-            const RtHitLite h = pb.hit[slot];
+            const uint32_t path = bucket[i];
+            const Ray r = load_ray(rays + path, slot);
+            const RtHitLite h = pb.hit[path];
+            t = thr[path];
             const uint32_t ty = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
             uint32_t mi;
             if (ty == RT_REF_SPHERE) mi = sc.sphere_meta[idx].material;
@@ -438,22 +429,23 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
             const Sampler smp = slot_sampler(pi, slot, it);
             const ShadeOut o = rt_shade_as<MAT, SOLID>(sc, m, r, rec, smp);
             if (MAT == RT_MAT_DIFFUSE_LIGHT) { // the only material whose emitted() is not black
-                PathAcc* acc = pb.acc + slot;
-                acc->rr += acc->tr * o.emitted.x;
-                acc->rg += acc->tg * o.emitted.y;
-                acc->rb += acc->tb * o.emitted.z;
+                double* rad = pb.rad + 3u * (size_t)slot;
+                rad[0] += t.r * o.emitted.x;
+                rad[1] += t.g * o.emitted.y;
+                rad[2] += t.b * o.emitted.z;
             }
             // a path that used its last bounce adds nothing more: ray_color(depth <= 0) is black (main.rs:52-54)
             if (o.did_scatter && it + 1u < pi.max_depth) {
                 alive = true;
-                store_ray(pb, slot, o.scattered);
-                PathAcc* acc = pb.acc + slot;
-                acc->tr *= o.attenuation.x; acc->tg *= o.attenuation.y; acc->tb *= o.attenuation.z;
+                scattered = o.scattered;
+                t.r *= o.attenuation.x; t.g *= o.attenuation.y; t.b *= o.attenuation.z;
             }
         }
-        const bool take[1] = {alive};
-        const uint32_t slots[1] = {slot};
-        block_append<1>(take, slots, next, next_counter, scratch);
+        const uint32_t j = block_reserve(alive, next_counter, scratch); // the path's number in the next bounce
+        if (alive) {
+            store_ray(next_rays + j, scattered, slot);
+            next_thr[j] = t;
+        }
     }
 }
 
@@ -463,9 +455,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_accumulate(PassInfo pi, PathBufs p
         const size_t o = (size_t)pi.pixmap[lp] * 3u;
         double r = sum[o], g = sum[o + 1], b = sum[o + 2];
         for (uint32_t s = 0; s < pi.S; ++s) {
-            const uint32_t slot = lp * pi.S + s;
-            const PathAcc* acc = pb.acc + slot;
-            r += acc->rr; g += acc->rg; b += acc->rb;
+            const double* rad = pb.rad + 3u * ((size_t)lp * pi.S + s);
+            r += rad[0]; g += rad[1]; b += rad[2];
         }
         sum[o] = r; sum[o + 1] = g; sum[o + 2] = b;
     }
@@ -544,9 +535,9 @@ struct rt_context {
     size_t lds_per_block = 65536; // most LDS one workgroup may use
     // path pool
     size_t cap_paths = 0;
-    double* f64pool = nullptr; // cap_paths PathRay records, then cap_paths PathAcc records
+    uint8_t* f64pool = nullptr; // 2 x cap_paths PathRay, 2 x cap_paths PathThr, 3 x cap_paths doubles of radiance
     RtHitLite* hit = nullptr;
-    uint32_t* u32pool = nullptr; // 2 live queues + RT_BUCKET_COUNT bucket queues, cap_paths each
+    uint32_t* u32pool = nullptr; // RT_BUCKET_COUNT bucket queues, cap_paths each
     uint32_t* counters = nullptr;
     size_t cap_counters = 0;
     uint32_t* error_flag = nullptr;
@@ -624,9 +615,9 @@ int ensure_paths(rt_context* ctx, size_t paths, uint32_t max_depth) {
         if (ctx->hit) hipFree(ctx->hit);
         if (ctx->u32pool) hipFree(ctx->u32pool);
         ctx->f64pool = nullptr; ctx->hit = nullptr; ctx->u32pool = nullptr; ctx->cap_paths = 0;
-        RT_HIP(hipMalloc((void**)&ctx->f64pool, paths * (sizeof(PathRay) + sizeof(PathAcc))), "hipMalloc path state");
+        RT_HIP(hipMalloc((void**)&ctx->f64pool, paths * (2 * sizeof(PathRay) + 2 * sizeof(PathThr) + 3 * sizeof(double))), "hipMalloc path state");
         RT_HIP(hipMalloc((void**)&ctx->hit, paths * sizeof(RtHitLite)), "hipMalloc hit records");
-        RT_HIP(hipMalloc((void**)&ctx->u32pool, paths * (2 + RT_BUCKET_COUNT) * sizeof(uint32_t)), "hipMalloc queues");
+        RT_HIP(hipMalloc((void**)&ctx->u32pool, paths * RT_BUCKET_COUNT * sizeof(uint32_t)), "hipMalloc queues");
         ctx->cap_paths = paths;
     }
     const size_t need = (size_t)(max_depth + 2) * RT_COUNTER_STRIDE;
@@ -890,13 +881,14 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
     if (rc != RT_OK) return rc;
 
     PathBufs pb;
-    pb.ray = (PathRay*)ctx->f64pool;
-    pb.acc = (PathAcc*)(pb.ray + ctx->cap_paths);
+    pb.ray[0] = (PathRay*)ctx->f64pool;
+    pb.ray[1] = pb.ray[0] + ctx->cap_paths;
+    pb.thr[0] = (PathThr*)(pb.ray[1] + ctx->cap_paths);
+    pb.thr[1] = pb.thr[0] + ctx->cap_paths;
+    pb.rad = (double*)(pb.thr[1] + ctx->cap_paths);
     pb.hit = ctx->hit;
     QueueSet qs;
-    qs.live[0] = ctx->u32pool;
-    qs.live[1] = ctx->u32pool + ctx->cap_paths;
-    qs.bucket = ctx->u32pool + 2 * ctx->cap_paths;
+    qs.bucket = ctx->u32pool;
     qs.bucket_cap = ctx->cap_paths;
     qs.counters = ctx->counters;
     qs.error_flag = ctx->error_flag;
