@@ -7,10 +7,11 @@
 //   per bounce it = 0 .. max_depth-1
 //     k_extend_tree          closest hit of every live path: persistent waves, one 1024-thread workgroup per CU,
 //                            per-lane stacks and the top of the node array in LDS
-//     k_bin                  misses take the background and end; hits are queued by what shading them runs
-//                            (material type x plain-colour or computed texture): 8 queues, one block-wide append
-//     k_shade<bucket>        rebuild the hit record, emitted + scatter, write the next ray, and compact the
-//                            surviving paths into the next iteration's queue (one atomic per workgroup)
+//     k_shade_main           misses take the background and end; hits on materials with a plain colour: rebuild the
+//                            hit record, emitted + scatter, and write the surviving path's next ray and throughput
+//                            as a record of the next bounce (one atomic per workgroup); hits on computed textures
+//                            (Perlin, image, checker) are queued by material type
+//     k_shade<bucket>        the same shading for one queue of computed-texture hits
 //   k_accumulate             per pixel, add its S sample radiances in sample order to the f64 sum buffer
 //
 // Path state is one 64-byte record per path and array (ray; throughput + radiance) plus a 16-byte hit record.
@@ -32,8 +33,8 @@
 
 #define RT_BLOCK 256
 #define RT_TREE_BLOCK 1024 /* k_extend_tree: one workgroup per CU, so that the whole CU shares one LDS copy of the top of the tree */
-#define RT_BIN_PER_THREAD 8  /* rays per thread in k_bin */
-#define RT_COUNTER_STRIDE 16u /* per iteration: [0] live paths entering it, [1+b] hits queued for shading bucket b */
+#define RT_COUNTER_STRIDE 16u /* per iteration: [0] paths entering it at the front of the arrays, [1+b] hits queued for shading bucket b, [RT_COUNTER_BACK] paths entering it at the back */
+#define RT_COUNTER_BACK 9u
 
 // ---- device structures ------------------------------------------------------------------------------------
 // Path state. The paths alive at a bounce are DENSE: path number i of the bounce owns record i of the bounce's ray,
@@ -61,6 +62,21 @@ struct QueueSet {
     uint32_t* counters;         // (max_depth + 2) * RT_COUNTER_STRIDE
     uint32_t* error_flag;       // bit 0: traversal stack overflow
 };
+
+// The paths entering a bounce are written from both ends of the record arrays: paths that left a surface from the
+// front, paths that scattered inside a medium from the back (they meet different parts of the scene, and waves that
+// hold one kind only diverge less: measured 10 % of traversal time). Path i of n = front + back is record i, or
+// counted down from the end.
+struct LiveSet {
+    uint32_t front, back, cap;
+    __device__ uint32_t n() const { return front + back; }
+    __device__ uint32_t record(uint32_t i) const { return i < front ? i : cap - 1u - (i - front); }
+};
+__device__ inline LiveSet live_set(const uint32_t* ctr, size_t cap) {
+    LiveSet l;
+    l.front = ctr[0]; l.back = ctr[RT_COUNTER_BACK]; l.cap = (uint32_t)cap;
+    return l;
+}
 
 struct LdsStack {
     uint32_t* base; // this lane's column: entry k at base[k * stride], stride = threads per block (conflict-free)
@@ -118,21 +134,26 @@ struct ArrayXi { // injected uniforms for rt_trace_first_hit
 
 // Hands every thread with `take` set a distinct position counted from *counter: ONE atomic per workgroup (a single
 // counter word takes only ~90 atomics per microsecond chip-wide, so per-wave appends of millions of waves would
-// serialise on it). `scratch` = RT_BLOCK/64 + 1 words of LDS. Every thread of the block must call it.
-__device__ inline uint32_t block_reserve(bool take, uint32_t* counter, uint32_t* scratch) {
+// serialise on it). Every thread of the block must call it.
+// `which` = 0 or 1 selects one of two counters; `scratch` = 2 * (RT_BLOCK/64 + 1) words of LDS.
+__device__ inline uint32_t block_reserve(bool take, uint32_t which, uint32_t* counter0, uint32_t* counter1, uint32_t* scratch) {
+    constexpr uint32_t W = RT_BLOCK / 64u;
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
-    const unsigned long long mask = __ballot(take);
-    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long m0 = __ballot(take && which == 0u), m1 = __ballot(take && which != 0u);
+    const uint32_t rank = (uint32_t)__popcll((which == 0u ? m0 : m1) & below);
     __syncthreads();
-    if (lane == 0u) scratch[wave] = (uint32_t)__popcll(mask);
+    if (lane == 0u) { scratch[wave] = (uint32_t)__popcll(m0); scratch[W + 1u + wave] = (uint32_t)__popcll(m1); }
     __syncthreads();
-    if (threadIdx.x == 0u) {
+    if (threadIdx.x < 2u) {
+        uint32_t* sc = scratch + threadIdx.x * (W + 1u);
         uint32_t total = 0u;
-        for (uint32_t w = 0; w < RT_BLOCK / 64u; ++w) { const uint32_t c = scratch[w]; scratch[w] = total; total += c; }
-        scratch[RT_BLOCK / 64u] = total ? atomicAdd(counter, total) : 0u;
+        for (uint32_t w = 0; w < W; ++w) { const uint32_t c = sc[w]; sc[w] = total; total += c; }
+        sc[W] = total ? atomicAdd(threadIdx.x == 0u ? counter0 : counter1, total) : 0u;
     }
     __syncthreads();
-    return scratch[RT_BLOCK / 64u] + scratch[wave] + rank;
+    const uint32_t* sc = scratch + (which == 0u ? 0u : W + 1u);
+    return sc[W] + sc[wave] + rank;
 }
 
 // R items per thread, each for one of Q queues (which[r] >= Q: none): one atomic per queue per call, two barriers.
@@ -235,7 +256,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtCameraDev cam, PassInfo p
 // world.hit(r, 0.001, INFINITY, rec) (main.rs:56) for every live path of iteration `it`, in two launches:
 //
 //   k_extend_tree   closest hit: the lock-step entries when a lane takes a ray, then the tree, persistent waves
-//   k_bin           misses take the background and end; hits are queued by material type and texture class
+//   k_shade_main    misses take the background and end; hits on plain-colour materials are shaded; the rest is queued
 
 // Persistent waves. Once rays are incoherent the number of box tests differs by an order of magnitude from
 // lane to lane, and box tests and leaf tests interleave differently in every lane. So:
@@ -252,8 +273,8 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
                                                                uint32_t n_cached) {
     extern __shared__ uint4 lds_tree[]; // stack_cap * blockDim.x words of stack, n_cached node records, the queue counter
     const PathRay* rays = pb.ray[it & 1u];
-    uint32_t* ctr = qs.counters + it * RT_COUNTER_STRIDE;
-    const uint32_t n = ctr[0];
+    const LiveSet alive_paths = live_set(qs.counters + it * RT_COUNTER_STRIDE, qs.bucket_cap);
+    const uint32_t n = alive_paths.n();
     if (n == 0u) return;
     // queue positions handed out in this workgroup so far: the 16 bytes behind the node records
     uint32_t& blk_taken = *(uint32_t*)(lds_tree + (size_t)stack_cap * blockDim.x / 4u + (size_t)n_cached * 4u);
@@ -301,7 +322,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             if (!active) {
                 const unsigned long long i = index_of(v0 + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)));
                 if (i < n) {
-                    path = (uint32_t)i;
+                    path = alive_paths.record((uint32_t)i);
                     s.r = load_ray(rays + path, slot);
                     s.best.t = RT_INF; s.best.ref = RT_REF_NONE; s.best.aux = 0u;
                     // the world entries every ray is tested against, by the lanes that just took a ray, in lock step
@@ -344,57 +365,12 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
     }
 }
 
-__global__ void __launch_bounds__(RT_BLOCK) k_bin(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it) {
-    __shared__ uint32_t lds[RT_BUCKET_COUNT * (RT_BLOCK / 64)];
-    const PathRay* rays = pb.ray[it & 1u];
-    const PathThr* thr = pb.thr[it & 1u];
-    uint32_t* ctr = qs.counters + it * RT_COUNTER_STRIDE;
-    const uint32_t n = ctr[0];
-    const uint32_t per_block = RT_BLOCK * RT_BIN_PER_THREAD;
-    // whole blocks iterate together: the append synchronises the block
-    for (uint32_t base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
-        uint32_t path[RT_BIN_PER_THREAD], bucket[RT_BIN_PER_THREAD];
-#pragma unroll
-        for (int r = 0; r < RT_BIN_PER_THREAD; ++r) {
-            const uint32_t i = base + (uint32_t)r * RT_BLOCK + threadIdx.x;
-            path[r] = i;
-            bucket[r] = 0xFFFFFFFFu;
-            if (i < n) {
-                const RtHitLite h = pb.hit[i];
-                if (h.ref == RT_REF_NONE) { // main.rs:56-58: return background; the path ends here
-                    uint32_t slot;
-                    const Ray ray = load_ray(rays + i, slot);
-                    const V3 bg = rt_background(pi.bg, pi.bg_mode, ray);
-                    const PathThr t = thr[i];
-                    double* rad = pb.rad + 3u * (size_t)slot;
-                    rad[0] += t.r * bg.x;
-                    rad[1] += t.g * bg.y;
-                    rad[2] += t.b * bg.z;
-                } else {
-                    uint32_t m;
-                    const uint32_t ty = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
-                    if (ty == RT_REF_SPHERE) m = sc.sphere_meta[idx].material;
-                    else if (ty == RT_REF_MSPHERE) m = sc.msphere_meta[idx].material;
-                    else if (ty == RT_REF_RECT) m = sc.rect_meta[idx].material;
-                    else if (ty == RT_REF_BOX) m = sc.box_meta[idx].material;
-                    else m = sc.media[idx].material;
-                    const uint32_t mt = sc.materials[m].type;
-                    const bool textured = mt == RT_MAT_LAMBERTIAN || mt == RT_MAT_DIFFUSE_LIGHT || mt == RT_MAT_ISOTROPIC;
-                    bucket[r] = rt_bucket_of(mt, textured ? sc.textures[sc.materials[m].tex].type : (uint32_t)RT_TEX_SOLID);
-                }
-            }
-        }
-        block_append_multi<RT_BIN_PER_THREAD, RT_BUCKET_COUNT>(bucket, path, qs.bucket, qs.bucket_cap, ctr + 1u, lds);
-        __syncthreads();
-    }
-}
-
 // emitted + scatter (main.rs:60-70) for every path of iteration `it` that hit a material of type MAT.
 template <uint32_t BUCKET>
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it) {
     constexpr uint32_t MAT = rt_bucket_material(BUCKET);
     constexpr bool SOLID = rt_bucket_solid(BUCKET);
-    __shared__ uint32_t scratch[RT_BLOCK / 64 + 1];
+    __shared__ uint32_t scratch[2 * (RT_BLOCK / 64 + 1)];
     const uint32_t* bucket = qs.bucket + (size_t)BUCKET * qs.bucket_cap;
     const uint32_t n = qs.counters[it * RT_COUNTER_STRIDE + 1u + BUCKET];
     const PathRay* rays = pb.ray[it & 1u];
@@ -402,6 +378,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
     PathRay* next_rays = pb.ray[(it + 1u) & 1u];
     PathThr* next_thr = pb.thr[(it + 1u) & 1u];
     uint32_t* next_counter = qs.counters + (it + 1u) * RT_COUNTER_STRIDE;
+    const uint32_t cap = (uint32_t)qs.bucket_cap;
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < n;
@@ -441,8 +418,92 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
                 t.r *= o.attenuation.x; t.g *= o.attenuation.y; t.b *= o.attenuation.z;
             }
         }
-        const uint32_t j = block_reserve(alive, next_counter, scratch); // the path's number in the next bounce
+        const uint32_t end = MAT == RT_MAT_ISOTROPIC ? 1u : 0u; // scattered inside a medium: back of the arrays
+        uint32_t j = block_reserve(alive, end, next_counter, next_counter + RT_COUNTER_BACK, scratch);
         if (alive) {
+            if (end) j = cap - 1u - j;
+            store_ray(next_rays + j, scattered, slot);
+            next_thr[j] = t;
+        }
+    }
+}
+
+// The body of ray_color after world.hit (main.rs:56-70) for every path of iteration `it`, straight from the hit records:
+// a miss takes the background and ends; a hit on a material with a plain-colour texture (or none) is shaded here and
+// now - these are nearly all hits, their code is short, and Lambertian and Isotropic share the same rejection loop, so
+// mixing them in a wave costs little; a hit on a computed texture (Perlin noise, image, checker) is queued for the
+// k_shade kernel of its bucket, which would otherwise drag its registers and code through every wave.
+__global__ void __launch_bounds__(RT_BLOCK) k_shade_main(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it) {
+    __shared__ uint32_t scratch[2 * (RT_BLOCK / 64 + 1)];
+    __shared__ uint32_t lds[RT_BUCKET_COUNT * (RT_BLOCK / 64)];
+    uint32_t* ctr = qs.counters + it * RT_COUNTER_STRIDE;
+    const LiveSet alive_paths = live_set(ctr, qs.bucket_cap);
+    const uint32_t n = alive_paths.n();
+    const uint32_t cap = alive_paths.cap;
+    const PathRay* rays = pb.ray[it & 1u];
+    const PathThr* thr = pb.thr[it & 1u];
+    PathRay* next_rays = pb.ray[(it + 1u) & 1u];
+    PathThr* next_thr = pb.thr[(it + 1u) & 1u];
+    uint32_t* next_counter = qs.counters + (it + 1u) * RT_COUNTER_STRIDE;
+    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
+        const uint32_t i = alive_paths.record(base + threadIdx.x);
+        uint32_t slot = 0u, end = 0u;
+        bool alive = false;
+        uint32_t later[1] = {0xFFFFFFFFu};
+        const uint32_t path[1] = {i};
+        Ray scattered;
+        PathThr t;
+        scattered.o = v3(0.0, 0.0, 0.0); scattered.d = v3(0.0, 0.0, 0.0); scattered.tm = 0.0;
+        t.r = 0.0; t.g = 0.0; t.b = 0.0; t.pad = 0.0;
+        if (base + threadIdx.x < n) {
+            const RtHitLite h = pb.hit[i];
+            const Ray r = load_ray(rays + i, slot);
+            t = thr[i];
+            end = RT_REF_TYPE(h.ref) == RT_REF_MEDIUM ? 1u : 0u; // scattered inside a medium: back of the arrays
+            double* rad = pb.rad + 3u * (size_t)slot;
+            if (h.ref == RT_REF_NONE) { // main.rs:56-58: return background; the path ends here
+                const V3 bg = rt_background(pi.bg, pi.bg_mode, r);
+                rad[0] += t.r * bg.x;
+                rad[1] += t.g * bg.y;
+                rad[2] += t.b * bg.z;
+            } else {
+                const uint32_t ty = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
+                uint32_t mi;
+                if (ty == RT_REF_SPHERE) mi = sc.sphere_meta[idx].material;
+                else if (ty == RT_REF_MSPHERE) mi = sc.msphere_meta[idx].material;
+                else if (ty == RT_REF_RECT) mi = sc.rect_meta[idx].material;
+                else if (ty == RT_REF_BOX) mi = sc.box_meta[idx].material;
+                else mi = sc.media[idx].material;
+                const RtMaterial m = sc.materials[mi];
+                const bool textured = m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_DIFFUSE_LIGHT || m.type == RT_MAT_ISOTROPIC;
+                const uint32_t bucket = rt_bucket_of(m.type, textured ? sc.textures[m.tex].type : (uint32_t)RT_TEX_SOLID);
+                if (!rt_bucket_solid(bucket) && bucket != RT_BUCKET_METAL && bucket != RT_BUCKET_DIELECTRIC) {
+                    later[0] = bucket;
+                } else {
+                    const HitRec rec = rt_reconstruct(sc, r, h, false);
+                    const Sampler smp = slot_sampler(pi, slot, it);
+                    const ShadeOut o = rt_shade_as<RT_MAT_COUNT, true>(sc, m, r, rec, smp);
+                    if (m.type == RT_MAT_DIFFUSE_LIGHT) { // the only material whose emitted() is not black
+                        rad[0] += t.r * o.emitted.x;
+                        rad[1] += t.g * o.emitted.y;
+                        rad[2] += t.b * o.emitted.z;
+                    }
+                    // a path that used its last bounce adds nothing more: ray_color(depth <= 0) is black (main.rs:52-54)
+                    if (o.did_scatter && it + 1u < pi.max_depth) {
+                        alive = true;
+                        scattered = o.scattered;
+                        t.r *= o.attenuation.x; t.g *= o.attenuation.y; t.b *= o.attenuation.z;
+                    }
+                }
+            }
+        }
+        if (__syncthreads_or(later[0] != 0xFFFFFFFFu)) {
+            block_append_multi<1, RT_BUCKET_COUNT>(later, path, qs.bucket, qs.bucket_cap, ctr + 1u, lds);
+            __syncthreads();
+        }
+        uint32_t j = block_reserve(alive, end, next_counter, next_counter + RT_COUNTER_BACK, scratch);
+        if (alive) {
+            if (end) j = cap - 1u - j;
             store_ray(next_rays + j, scattered, slot);
             next_thr[j] = t;
         }
@@ -547,7 +608,7 @@ struct rt_context {
     size_t pm_cap = 0;
     std::vector<hipEvent_t> events;
     // k_extend thresholds (lanes of a wave): refill once this many lanes are out of work, test leaves once this many wait
-    uint32_t tune_refill = 16, tune_leaf = 32;
+    uint32_t tune_refill = 48, tune_leaf = 32;
 };
 
 namespace {
@@ -939,15 +1000,10 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
                                ctx->tune_refill, ctx->tune_leaf, n_cached);
             tm.end(a, 1);
             a = tm.begin();
-            hipLaunchKernelGGL(k_bin, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);
+            hipLaunchKernelGGL(k_shade_main, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);
             tm.end(a, 9);
-            launch_shade<RT_BUCKET_LAMBERTIAN_SOLID>(ctx, &local, pi, pb, qs, it, g_sh, tm);
             launch_shade<RT_BUCKET_LAMBERTIAN_TEX>(ctx, &local, pi, pb, qs, it, g_sh, tm);
-            launch_shade<RT_BUCKET_METAL>(ctx, &local, pi, pb, qs, it, g_sh, tm);
-            launch_shade<RT_BUCKET_DIELECTRIC>(ctx, &local, pi, pb, qs, it, g_sh, tm);
-            launch_shade<RT_BUCKET_LIGHT_SOLID>(ctx, &local, pi, pb, qs, it, g_sh, tm);
             launch_shade<RT_BUCKET_LIGHT_TEX>(ctx, &local, pi, pb, qs, it, g_sh, tm);
-            launch_shade<RT_BUCKET_ISOTROPIC_SOLID>(ctx, &local, pi, pb, qs, it, g_sh, tm);
             launch_shade<RT_BUCKET_ISOTROPIC_TEX>(ctx, &local, pi, pb, qs, it, g_sh, tm);
         }
         a = tm.begin();
@@ -961,11 +1017,12 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
             stats->passes += 1;
             stats->camera_samples += paths;
             uint64_t seg = 0;
-            for (uint32_t it = 0; it < p->max_depth; ++it) seg += host_counters[(size_t)it * RT_COUNTER_STRIDE];
+            for (uint32_t it = 0; it < p->max_depth; ++it)
+                seg += (uint64_t)host_counters[(size_t)it * RT_COUNTER_STRIDE] + host_counters[(size_t)it * RT_COUNTER_STRIDE + RT_COUNTER_BACK];
             stats->ray_segments += seg;
             if (getenv("RT_DEBUG")) {
                 fprintf(stderr, "rt: live paths per bounce:");
-                for (uint32_t it = 0; it < p->max_depth; ++it) fprintf(stderr, " %u", host_counters[(size_t)it * RT_COUNTER_STRIDE]);
+                for (uint32_t it = 0; it < p->max_depth; ++it) fprintf(stderr, " %u+%u", host_counters[(size_t)it * RT_COUNTER_STRIDE], host_counters[(size_t)it * RT_COUNTER_STRIDE + RT_COUNTER_BACK]);
                 fprintf(stderr, "\n");
             }
             stats->medium_tests += seg * sc->hdr.n_media;
