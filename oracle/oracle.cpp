@@ -128,13 +128,30 @@ static Vec3 refract(Vec3 uv, Vec3 n, double etai_over_etat) {                  /
     Vec3 r_out_parallel = -n * std::sqrt(std::fabs(1.0 - r_out_perp.squared_length()));
     return r_out_perp + r_out_parallel;
 }
+// Draws of the scatter rejection loop: xoshiro128++ seeded by the Philox block (S_SCATTER, slot 0) of the sample's
+// bounce; every uniform is 53 bits from two successive outputs (first = high word).
+struct Xoshiro128pp {
+    uint32_t s[4];
+    static uint32_t rotl(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+    uint32_t next() {
+        const uint32_t result = rotl(s[0] + s[3], 7) + s[0];
+        const uint32_t t = s[1] << 9;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = rotl(s[3], 11);
+        return result;
+    }
+    double unit() { uint32_t hi = next(); uint32_t lo = next(); return to_unit(hi, lo); }
+};
 static Vec3 random_in_unit_sphere(const Rng& rng) { // vec3.rs:73-80
+    U4 c{rng.sample, (rng.bounce << 16) | S_SCATTER, 0u, (uint32_t)(rng.seed >> 32)};
+    U4 o = philox(c, rng.pixel, (uint32_t)rng.seed);
+    Xoshiro128pp g{{o.a, o.b, o.c, o.d}};
+    if ((g.s[0] | g.s[1] | g.s[2] | g.s[3]) == 0u) g.s[0] = 1u;
     Vec3 p;
     for (uint32_t k = 0; k < 4096; ++k) {
-        double a, b, c, unused;
-        rng.draw2(S_SCATTER, 2 * k, a, b);
-        rng.draw2(S_SCATTER, 2 * k + 1, c, unused);
-        p = Vec3(in_range(a, -1.0, 1.0), in_range(b, -1.0, 1.0), in_range(c, -1.0, 1.0));
+        double a = g.unit(), b = g.unit(), c2 = g.unit();
+        p = Vec3(in_range(a, -1.0, 1.0), in_range(b, -1.0, 1.0), in_range(c2, -1.0, 1.0));
         if (p.squared_length() < 1.0) return p;
     }
     return p;

@@ -131,14 +131,45 @@ RT_HD double sampler_draw1(const Sampler& s, uint32_t stream, uint32_t attempt) 
 // random_double(low, high) (rtweekend.rs:19-22): uniform on [low, high)
 RT_HD double rt_range(double u, double lo, double hi) { return lo + (hi - lo) * u; }
 
-// Vec3::random_in_unit_sphere (vec3.rs:73-80): rejection from [-1,1)^3; attempt k uses counter
-// slots 2k (x, y) and 2k+1 (z).
+// The draws of a rejection loop whose length is not known in advance. A wave runs such a loop until its slowest lane
+// accepts (about six rounds for a 52 % acceptance rate), so the cost per round matters more than anything else in the
+// shading kernels. One Philox block (stream, slot 0) seeds a xoshiro128++ generator (Blackman & Vigna, 32-bit
+// state words: add, rotate, shift, xor only), which then supplies the 53-bit uniforms: a round costs a third of what
+// two Philox blocks cost, and the sequence is still a pure function of (pixel, sample, bounce, stream, seed).
+struct SubStream {
+    uint32_t s0, s1, s2, s3;
+};
+RT_HD SubStream substream_make(const Sampler& s, uint32_t stream) {
+    const Philox4 p = philox4x32_10(s.sample, (s.bounce << 16) | stream, 0u, s.seed_hi, s.pixel, s.seed_lo);
+    SubStream g;
+    g.s0 = p.v[0]; g.s1 = p.v[1]; g.s2 = p.v[2]; g.s3 = p.v[3];
+    if ((g.s0 | g.s1 | g.s2 | g.s3) == 0u) g.s0 = 1u; // the one state xoshiro cannot leave
+    return g;
+}
+RT_HD uint32_t substream_next(SubStream& g) {
+    const uint32_t a = g.s0 + g.s3;
+    const uint32_t result = ((a << 7) | (a >> 25)) + g.s0;
+    const uint32_t t = g.s1 << 9;
+    g.s2 ^= g.s0;
+    g.s3 ^= g.s1;
+    g.s1 ^= g.s2;
+    g.s0 ^= g.s3;
+    g.s2 ^= t;
+    g.s3 = (g.s3 << 11) | (g.s3 >> 21);
+    return result;
+}
+RT_HD double substream_u01(SubStream& g) {
+    const uint32_t hi = substream_next(g);
+    const uint32_t lo = substream_next(g);
+    return rt_u01(hi, lo);
+}
+// Vec3::random_in_unit_sphere (vec3.rs:73-80): rejection from [-1,1)^3; x, y, z of each attempt are the next three
+// uniforms of the scatter sub-stream.
 RT_HD V3 rt_random_in_unit_sphere(const Sampler& s) {
     V3 p = v3(0.0, 0.0, 0.0);
+    SubStream g = substream_make(s, 3u /*RT_STREAM_SCATTER*/);
     for (uint32_t k = 0; k < 4096u; ++k) {
-        double ux, uy, uz, spare;
-        sampler_draw2(s, 3u /*RT_STREAM_SCATTER*/, 2u * k, ux, uy);
-        sampler_draw2(s, 3u, 2u * k + 1u, uz, spare);
+        const double ux = substream_u01(g), uy = substream_u01(g), uz = substream_u01(g);
         p = v3(rt_range(ux, -1.0, 1.0), rt_range(uy, -1.0, 1.0), rt_range(uz, -1.0, 1.0));
         if (v3_sqlen(p) < 1.0) return p;
     }
