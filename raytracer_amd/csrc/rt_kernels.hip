@@ -42,7 +42,8 @@
 // path gets in the next bounce's arrays (two sets, alternating). So every kernel streams through contiguous records
 // and nothing is read through an index; what ties a record to its pixel is the slot number it carries. Only the
 // radiance array is indexed by slot, and it is written once per path, when the path ends.
-struct PathRay { double ox, oy, oz, dx, dy, dz, tm; uint32_t slot, pad; }; // current ray (ray.rs:5-9) + slot = local_pixel * S + sample
+struct PathRay { double ox, oy, oz, dx, dy, dz, tm; uint32_t slot, pixel; }; // current ray (ray.rs:5-9) + whose it is: slot = local_pixel * S + sample, pixel = y * width + x
+struct PathId { uint32_t slot, pixel; };
 struct PathThr { double r, g, b, pad; };                                  // product of the attenuations so far (main.rs:70)
 struct PathBufs {
     PathRay* ray[2];  // [it & 1]: rays entering bounce it
@@ -124,7 +125,8 @@ struct CachedNodes {
 struct PassInfo;
 struct PhiloxXi { // the uniform a ConstantMedium draws (constant_medium.rs:53) for path `slot` at bounce `bounce`
     const PassInfo* pi;
-    uint32_t slot, bounce;
+    PathId id;
+    uint32_t bounce;
     __device__ double operator()(uint32_t medium_index) const;
 };
 struct ArrayXi { // injected uniforms for rt_trace_first_hit
@@ -194,19 +196,20 @@ __device__ inline void block_append_multi(const uint32_t (&which)[R], const uint
         if (which[r] < (uint32_t)Q) qbase[(size_t)which[r] * qcap + lds[which[r] * W + wave] + rank[r]] = slot[r];
 }
 
-__device__ inline Ray load_ray(const PathRay* rec, uint32_t& slot) {
+__device__ inline Ray load_ray(const PathRay* rec, PathId& id) {
     Ray r;
     const double2* q = (const double2*)rec;
     const double2 a = q[0], b = q[1], c = q[2], d = q[3];
     r.o = v3(a.x, a.y, b.x);
     r.d = v3(b.y, c.x, c.y);
     r.tm = d.x;
-    slot = (uint32_t)__double_as_longlong(d.y);
+    const unsigned long long w = (unsigned long long)__double_as_longlong(d.y);
+    id.slot = (uint32_t)w; id.pixel = (uint32_t)(w >> 32);
     return r;
 }
 struct SlotRay { // the world-space ray of a path, re-read from its record on demand
     const PathRay* rec;
-    __device__ Ray operator()() const { uint32_t slot; return load_ray(rec, slot); }
+    __device__ Ray operator()() const { PathId id; return load_ray(rec, id); }
 };
 struct HeldRay { // the world-space ray, still held in registers
     const Ray* r;
@@ -220,20 +223,18 @@ struct QueryRay {
         return r;
     }
 };
-__device__ inline void store_ray(PathRay* rec, const Ray& r, uint32_t slot) {
+__device__ inline void store_ray(PathRay* rec, const Ray& r, PathId id) {
     double2* q = (double2*)rec;
     q[0] = make_double2(r.o.x, r.o.y);
     q[1] = make_double2(r.o.z, r.d.x);
     q[2] = make_double2(r.d.y, r.d.z);
-    q[3] = make_double2(r.tm, __longlong_as_double((long long)slot));
+    q[3] = make_double2(r.tm, __longlong_as_double((long long)(((unsigned long long)id.pixel << 32) | id.slot)));
 }
-__device__ inline Sampler slot_sampler(const PassInfo& pi, uint32_t slot, uint32_t bounce) {
-    const uint32_t lp = slot / pi.S, s = slot - lp * pi.S;
-    return sampler_make(pi.pixmap[lp], pi.sample_offset + s, bounce, pi.seed);
+__device__ inline Sampler slot_sampler(const PassInfo& pi, PathId id, uint32_t bounce) {
+    return sampler_make(id.pixel, pi.sample_offset + id.slot % pi.S, bounce, pi.seed);
 }
-
 __device__ double PhiloxXi::operator()(uint32_t medium_index) const {
-    return sampler_draw1(slot_sampler(*pi, slot, bounce), RT_STREAM_MEDIUM0 + medium_index, 0u);
+    return sampler_draw1(slot_sampler(*pi, id, bounce), RT_STREAM_MEDIUM0 + medium_index, 0u);
 }
 
 // ---- kernels ------------------------------------------------------------------------------------------------
@@ -245,7 +246,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtCameraDev cam, PassInfo p
         const uint32_t y = pixel / pi.width, x = pixel - y * pi.width;
         const Sampler smp = sampler_make(pixel, pi.sample_offset + s, 0u, pi.seed);
         const Ray r = rt_primary_ray(cam, x, y, pi.width, pi.height, smp, pi.compat);
-        store_ray(pb.ray[0] + slot, r, slot); // before the first bounce path number = slot
+        PathId id;
+        id.slot = slot; id.pixel = pixel;
+        store_ray(pb.ray[0] + slot, r, id); // before the first bounce path number = slot
         PathThr one;
         one.r = 1.0; one.g = 1.0; one.b = 1.0; one.pad = 0.0;
         pb.thr[0][slot] = one;
@@ -299,7 +302,9 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
     RtTrav s;
     s.cur = RT_REF_NONE;
     s.best.t = RT_INF; s.best.ref = RT_REF_NONE; s.best.aux = 0u;
-    uint32_t slot = 0u, path = 0u;
+    PathId id;
+    id.slot = 0u; id.pixel = 0u;
+    uint32_t path = 0u;
     bool active = false;    // tracing a ray
     bool exhausted = false; // wave-uniform: the queue has no more rays
     // pieces of 2^shift queue indices, about 8 per workgroup, between 256 and 4096 indices each
@@ -323,13 +328,13 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
                 const unsigned long long i = index_of(v0 + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)));
                 if (i < n) {
                     path = alive_paths.record((uint32_t)i);
-                    s.r = load_ray(rays + path, slot);
+                    s.r = load_ray(rays + path, id);
                     s.best.t = RT_INF; s.best.ref = RT_REF_NONE; s.best.aux = 0u;
                     // the world entries every ray is tested against, by the lanes that just took a ray, in lock step
                     HeldRay held;
                     held.r = &s.r;
                     PhiloxXi xi;
-                    xi.pi = &pi; xi.slot = slot; xi.bounce = it;
+                    xi.pi = &pi; xi.id = id; xi.bounce = it;
                     rt_extend_flat(sc, held, 0.001, s.best, xi, false);
                     s.slab = rt_slab_of(s.r);
                     s.cur = sc.world_tree;
@@ -353,7 +358,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             SlotRay ray_of;
             ray_of.rec = rays + path;
             PhiloxXi xi;
-            xi.pi = &pi; xi.slot = slot; xi.bounce = it;
+            xi.pi = &pi; xi.id = id; xi.bounce = it;
             rt_trav_visit(sc, s, st, 0.001, xi, false, ray_of);
         }
         if (active && s.cur == RT_REF_NONE) { // finished: publish the closest hit
@@ -382,7 +387,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < n;
-        uint32_t slot = 0u;
+        PathId id;
+        id.slot = 0u; id.pixel = 0u;
         bool alive = false;
         Ray scattered;
         PathThr t;
@@ -390,7 +396,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
         t.r = 0.0; t.g = 0.0; t.b = 0.0; t.pad = 0.0;
         if (active) {
             const uint32_t path = bucket[i];
-            const Ray r = load_ray(rays + path, slot);
+            const Ray r = load_ray(rays + path, id);
             const RtHitLite h = pb.hit[path];
             t = thr[path];
             const uint32_t ty = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
@@ -403,10 +409,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
             const RtMaterial m = sc.materials[mi];
             const bool uv = (SOLID || MAT == RT_MAT_METAL || MAT == RT_MAT_DIELECTRIC) ? false : rt_material_reads_uv(sc, m);
             const HitRec rec = rt_reconstruct(sc, r, h, uv);
-            const Sampler smp = slot_sampler(pi, slot, it);
+            const Sampler smp = slot_sampler(pi, id, it);
             const ShadeOut o = rt_shade_as<MAT, SOLID>(sc, m, r, rec, smp);
             if (MAT == RT_MAT_DIFFUSE_LIGHT) { // the only material whose emitted() is not black
-                double* rad = pb.rad + 3u * (size_t)slot;
+                double* rad = pb.rad + 3u * (size_t)id.slot;
                 rad[0] += t.r * o.emitted.x;
                 rad[1] += t.g * o.emitted.y;
                 rad[2] += t.b * o.emitted.z;
@@ -422,7 +428,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
         uint32_t j = block_reserve(alive, end, next_counter, next_counter + RT_COUNTER_BACK, scratch);
         if (alive) {
             if (end) j = cap - 1u - j;
-            store_ray(next_rays + j, scattered, slot);
+            store_ray(next_rays + j, scattered, id);
             next_thr[j] = t;
         }
     }
@@ -447,7 +453,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_main(DScene sc, PassInfo pi,
     uint32_t* next_counter = qs.counters + (it + 1u) * RT_COUNTER_STRIDE;
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
         const uint32_t i = alive_paths.record(base + threadIdx.x);
-        uint32_t slot = 0u, end = 0u;
+        PathId id;
+        id.slot = 0u; id.pixel = 0u;
+        uint32_t end = 0u;
         bool alive = false;
         uint32_t later[1] = {0xFFFFFFFFu};
         const uint32_t path[1] = {i};
@@ -457,10 +465,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_main(DScene sc, PassInfo pi,
         t.r = 0.0; t.g = 0.0; t.b = 0.0; t.pad = 0.0;
         if (base + threadIdx.x < n) {
             const RtHitLite h = pb.hit[i];
-            const Ray r = load_ray(rays + i, slot);
+            const Ray r = load_ray(rays + i, id);
             t = thr[i];
             end = RT_REF_TYPE(h.ref) == RT_REF_MEDIUM ? 1u : 0u; // scattered inside a medium: back of the arrays
-            double* rad = pb.rad + 3u * (size_t)slot;
+            double* rad = pb.rad + 3u * (size_t)id.slot;
             if (h.ref == RT_REF_NONE) { // main.rs:56-58: return background; the path ends here
                 const V3 bg = rt_background(pi.bg, pi.bg_mode, r);
                 rad[0] += t.r * bg.x;
@@ -481,7 +489,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_main(DScene sc, PassInfo pi,
                     later[0] = bucket;
                 } else {
                     const HitRec rec = rt_reconstruct(sc, r, h, false);
-                    const Sampler smp = slot_sampler(pi, slot, it);
+                    const Sampler smp = slot_sampler(pi, id, it);
                     const ShadeOut o = rt_shade_as<RT_MAT_COUNT, true>(sc, m, r, rec, smp);
                     if (m.type == RT_MAT_DIFFUSE_LIGHT) { // the only material whose emitted() is not black
                         rad[0] += t.r * o.emitted.x;
@@ -504,7 +512,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_main(DScene sc, PassInfo pi,
         uint32_t j = block_reserve(alive, end, next_counter, next_counter + RT_COUNTER_BACK, scratch);
         if (alive) {
             if (end) j = cap - 1u - j;
-            store_ray(next_rays + j, scattered, slot);
+            store_ray(next_rays + j, scattered, id);
             next_thr[j] = t;
         }
     }
