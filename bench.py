@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per GPU per step")
+    ap.add_argument("--spp", type=int, default=256, help="samples per pixel per GPU per step")
     ap.add_argument("--scene", default="final_scene")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     args = ap.parse_args()
