@@ -24,15 +24,15 @@ segments = json.loads(line)["roofline"]["segments_per_launch"] * launches
 fetch, write = tot["FETCH_SIZE"] * 1024.0, tot["WRITE_SIZE"] * 1024.0
 out = {
     "kernel": "k_extend_tree",
-    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-include-regex k_extend_tree -- python3 tools/render_once.py --spp 64 (separate passes)",
+    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-include-regex k_extend_tree -- python3 tools/render_once.py --spp 256 (separate passes)",
     "launches": launches,
     "FETCH_SIZE_KB_sum": tot["FETCH_SIZE"],
     "WRITE_SIZE_KB_sum": tot["WRITE_SIZE"],
     "hbm_bytes_per_launch": (fetch + write) / launches,
-    "note": "FETCH_SIZE taken as reported (KB): the gfx950 x2 correction applies to 16-B-per-lane streaming reads; this kernel "
-            "reads one 64-byte record per lane from scattered slots, an uncalibrated pattern. One pass = %d launches, %.1f M "
-            "segments: %.0f B fetched and %.0f B written per segment against 60 B and 16 B algorithmic (the rest: 64-byte "
-            "records and lines, scene data that misses L2)." % (launches, segments / 1e6, fetch / segments, write / segments),
+    "note": "FETCH_SIZE taken as reported (KB). The kernel reads 64-byte ray records, 16 B per lane per load, lanes on "
+            "consecutive records: if the gfx950 x2 correction for wide streaming reads applies, fetched bytes are twice the "
+            "figure. One pass = %d launches, %.1f M segments: %.0f B fetched (as reported) and %.0f B written per segment "
+            "against 56 B and 16 B algorithmic." % (launches, segments / 1e6, fetch / segments, write / segments),
 }
 for name in (tag + "_extend_hbm_traffic.json", "extend_hbm_traffic.json"):
     json.dump(out, open(os.path.join(dst, name), "w"), indent=1)
