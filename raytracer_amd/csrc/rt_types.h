@@ -37,7 +37,7 @@ enum RtRefType : uint32_t {
 
 #define RT_NO_PARENT (-1)
 #define RT_MAX_CHAIN 4   /* deepest Translate/RotateY nesting above any primitive */
-#define RT_STACK_CAP 40  /* per-lane traversal stack entries (LDS) */
+#define RT_STACK_CAP 39  /* per-lane traversal stack entries: 39 x 1024 lanes x 4 B + the queue counter fill the 160 KB of LDS a workgroup can have */
 
 // ---- records -------------------------------------------------------------------------------------
 // 64-byte BVH node: the boxes of BOTH children and their refs, so that one fetch decides both descents and the
