@@ -92,3 +92,26 @@ def test_sample_order_and_offsets_compose():
     o_part, _ = osc.render(info.camera, p, 2, threads=3)
     o_part, _ = osc.render(info.camera, p, 4, sample_offset=2, threads=2, rgb_sum=o_part)
     assert np.array_equal(o_whole, o_part)                         # and the oracle does not depend on its thread count
+
+
+@pytest.mark.parametrize("name", ["final_scene", "random_scene", "cornell_smoke", "my_scene"])
+def test_reference_topology_trees_find_the_same_hits(name):
+    """Builder flag bit 1 keeps every BvhNode as BvhNode::new builds it (bvh.rs:15-66) instead of dissolving it into a
+    surface-area-heuristic tree: the closest hits must not depend on which tree is walked (exact ties aside)."""
+    _, info, blob, desc = util.build_scene(name)
+    _, _, blob_ref, desc_ref = util.build_scene(name, flags=2)
+    assert blob != blob_ref
+    osc = ck.OracleScene(desc, share_bvh_axes=True)
+    p = api.params_from_info(info, width=40, height=30, seed=util.RENDER_SEED)
+    cam = ck.oracle_generate_rays(info.camera, p, 0)
+    rng = np.random.default_rng(11)
+    first = osc.trace_first_hit(cam, rng.random((len(cam), osc.n_media)) if osc.n_media else None)
+    rays = util.ray_suite(cam, first, rng)
+    xi = rng.random((len(rays), osc.n_media)) if osc.n_media else None
+    a, _ = ck.hostsim_trace_first_hit(blob, rays, xi)
+    b, _ = ck.hostsim_trace_first_hit(blob_ref, rays, xi)
+    rep = util.first_hit_report(a, b)
+    assert rep["prim_match"] == 1.0 and rep["t_bit_equal"] == 1.0 and rep["ties"] < 0.02, rep
+    want = osc.trace_first_hit(rays, xi)
+    rep = util.first_hit_report(b, want)
+    assert rep["prim_match"] == 1.0 and rep["t_bit_equal"] == 1.0, rep

@@ -50,6 +50,29 @@ def test_gate1_first_hit(gpu_ctx, name):
     scene.close()
 
 
+def test_reference_topology_trees_on_the_gpu(gpu_ctx):
+    """Builder flag bit 1 (every BvhNode keeps the reference's topology): same hits, same image sums."""
+    _, info, blob, desc = util.build_scene("final_scene", flags=2)
+    osc = ck.OracleScene(desc, share_bvh_axes=True)
+    scene = gpu_ctx.upload(blob)
+    p = api.params_from_info(info, width=120, height=90, seed=util.RENDER_SEED)
+    rng = np.random.default_rng(23)
+    cam = gpu_ctx.generate_rays(info.camera, p, 0)
+    xi0 = rng.random((len(cam), osc.n_media))
+    rays = util.ray_suite(cam, osc.trace_first_hit(cam, xi0), rng, n_secondary=20000)
+    xi = rng.random((len(rays), osc.n_media))
+    rep = util.first_hit_report(gpu_ctx.trace_first_hit(scene, rays, xi), osc.trace_first_hit(rays, xi))
+    assert rep["prim_match"] >= 0.9999 and rep["t_rel_max"] <= 1e-5 and rep["t_bit_equal"] >= 0.98, rep
+    _, _, blob_sah, _ = util.build_scene("final_scene")
+    scene_sah = gpu_ctx.upload(blob_sah)
+    p = api.params_from_info(info, width=64, height=48, seed=util.RENDER_SEED, spp_per_pass=4)
+    a = gpu_ctx.render(scene, info.camera, p, 8)
+    b = gpu_ctx.render(scene_sah, info.camera, p, 8)
+    assert float((util.rel_err(a, b) > 1e-9).mean()) <= 0.002      # paths are identical unless a tie resolves differently
+    scene.close()
+    scene_sah.close()
+
+
 def test_first_hit_edge_cases(gpu_ctx):
     _, info, blob, desc = util.build_scene("cornell_smoke")
     scene = gpu_ctx.upload(blob)
