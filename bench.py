@@ -64,11 +64,15 @@ def cpu_baseline(desc, info, seed, target_seconds):
     _, st = osc.render(info.camera, p, 1, threads=cores)                       # calibration: 1 spp
     spp = int(max(1, min(64, target_seconds / max(st.seconds, 1e-3))))
     _, st = osc.render(info.camera, p, spp, sample_offset=1, threads=cores)
+    # and as the reference runs by default: 2 worker threads over 16 row bands (main.rs:128,143-152), 1 spp
+    _, st2 = osc.render(info.camera, p, 1, sample_offset=1 + spp, threads=2, jobs=16)
     return {
         "value": st.ray_segments / st.seconds, "unit": "rays/s", "cores": cores, "kind": "port",
         "samples_per_sec": st.camera_samples / st.seconds,
         "sample": "oracle (C++ f64 restatement of the reference renderer, %d threads, %d row-band jobs), final_scene "
                   "%dx%d, %d spp, depth %d: %.1f s" % (st.threads, st.jobs, info.width, info.height, spp, info.max_depth, st.seconds),
+        "reference_default": {"value": st2.ray_segments / st2.seconds, "unit": "rays/s", "cores": 2,
+                              "sample": "the same with the reference's default 2 workers / 16 jobs, 1 spp: %.1f s" % st2.seconds},
     }
 
 

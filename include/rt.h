@@ -196,6 +196,7 @@ int rt_device_alloc(rt_context*, size_t nbytes, void** d_ptr);
 int rt_device_free(rt_context*, void* d_ptr);
 int rt_device_memset(rt_context*, void* d_ptr, int value, size_t nbytes);
 int rt_device_download(rt_context*, void* host_dst, const void* d_src, size_t nbytes);
+int rt_device_upload(rt_context*, void* d_dst, const void* host_src, size_t nbytes);
 
 #ifdef __cplusplus
 }

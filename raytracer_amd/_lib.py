@@ -106,6 +106,7 @@ PROTOTYPES = {
     "rt_device_free": (C.c_int, [_P, _P]),
     "rt_device_memset": (C.c_int, [_P, _P, C.c_int, C.c_size_t]),
     "rt_device_download": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "rt_device_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
 }
 
 

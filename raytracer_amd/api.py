@@ -214,6 +214,23 @@ class Context:
         assert rgb_sum.size == n * 3
         return (rgb_sum, rgb8) if want_rgb8 else rgb_sum
 
+    def render_more(self, scene, camera, params, rgb_sum, samples_done, spp, stats=None):
+        """Continues a render: adds samples [samples_done, samples_done + spp) of every pixel to the host array
+        rgb_sum (height, width, 3) and returns it. Random numbers are keyed on (pixel, sample, bounce), so the result is
+        bit-identical to having rendered samples_done + spp in one call: a saved sum is a checkpoint."""
+        rgb_sum = np.ascontiguousarray(rgb_sum, dtype=np.float64)
+        assert rgb_sum.shape == (params.height, params.width, 3)
+        d = C.c_void_p()
+        self._chk(lib.rt_device_alloc(self._c, rgb_sum.nbytes, C.byref(d)))
+        try:
+            self._chk(lib.rt_device_upload(self._c, d, rgb_sum.ctypes.data, rgb_sum.nbytes))
+            self.render_accumulate(scene, camera, params, samples_done, spp, d.value, stats)
+            out = np.empty_like(rgb_sum)
+            self._chk(lib.rt_device_download(self._c, out.ctypes.data, d, out.nbytes))
+        finally:
+            lib.rt_device_free(self._c, d)
+        return out
+
     def render_accumulate(self, scene, camera, params, sample_offset, spp, d_rgb_sum, stats=None):
         """d_rgb_sum: integer device address of width*height*3 doubles (e.g. torch_tensor.data_ptr())."""
         self._chk(lib.rt_render_accumulate(self._c, scene._h, C.byref(camera), C.byref(params), sample_offset, spp,
@@ -225,3 +242,23 @@ def tonemap(rgb_sum, spp):
     out = np.zeros(rgb_sum.shape, dtype=np.uint8)
     lib.rt_tonemap(rgb_sum.ctypes.data, rgb_sum.size // 3, float(spp), out.ctypes.data)
     return out
+
+
+def write_ppm(path, rgb8):
+    """Binary PPM of an (height, width, 3) u8 image, rows in the order the reference stores them (main.rs:170,244-251:
+    image row y = the v = y / (height - 1) scanline, no flip)."""
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    assert rgb8.ndim == 3 and rgb8.shape[2] == 3
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (rgb8.shape[1], rgb8.shape[0]))
+        f.write(rgb8.tobytes())
+
+
+def save_checkpoint(path, rgb_sum, samples_done, seed):
+    """The linear radiance sums and how many samples per pixel they hold: enough to resume with Context.render_more."""
+    np.savez(path, rgb_sum=np.asarray(rgb_sum, dtype=np.float64), samples_done=np.uint32(samples_done), seed=np.uint64(seed))
+
+
+def load_checkpoint(path):
+    with np.load(path, allow_pickle=False) as z:
+        return z["rgb_sum"].copy(), int(z["samples_done"]), int(z["seed"])

@@ -1101,5 +1101,11 @@ int rt_device_download(rt_context* ctx, void* host_dst, const void* d_src, size_
     RT_HIP(hipMemcpy(host_dst, d_src, nbytes, hipMemcpyDeviceToHost), "hipMemcpy");
     return RT_OK;
 }
+int rt_device_upload(rt_context* ctx, void* d_dst, const void* host_src, size_t nbytes) {
+    if (!ctx) return RT_ERR_INVALID;
+    RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    RT_HIP(hipMemcpy(d_dst, host_src, nbytes, hipMemcpyHostToDevice), "hipMemcpy");
+    return RT_OK;
+}
 
 } // extern "C"

@@ -237,3 +237,17 @@ def test_one_million_sphere_scene_compiles():
     assert h["sections"]["nodes"][1] == 999_999 and h["world_flat"] >> 28 == 8
     assert h["sections"]["spheres"][1] + h["sections"]["mspheres"][1] == 1_000_001
     assert h["stack_need"] <= 40 and info.width == 3840 and info.height == 2160
+
+
+def test_ppm_writer_and_checkpoint_round_trip(tmp_path):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    api.write_ppm(str(tmp_path / "a.ppm"), img)
+    data = open(str(tmp_path / "a.ppm"), "rb").read()
+    assert data == b"P6\n7 5\n255\n" + img.tobytes()
+    s = rng.random((5, 7, 3))
+    api.save_checkpoint(str(tmp_path / "c.npz"), s, 12, 0x5EED0002)
+    got, done, seed = api.load_checkpoint(str(tmp_path / "c.npz"))
+    assert got.tobytes() == s.tobytes() and done == 12 and seed == 0x5EED0002
+    # the pixel conversion of main.rs:172-189: sqrt(sum / spp) clamped to 0.999, times 255.999, truncated
+    assert api.tonemap(np.array([[[0.0, 4.0, 1.0]]]), 4).tolist() == [[[0, 255, 127]]]

@@ -73,6 +73,23 @@ def test_reference_topology_trees_on_the_gpu(gpu_ctx):
     scene_sah.close()
 
 
+def test_checkpoint_and_resume_is_bit_identical(gpu_ctx, tmp_path):
+    _, info, blob, _ = util.build_scene("final_scene")
+    scene = gpu_ctx.upload(blob)
+    p = api.params_from_info(info, width=48, height=32, seed=util.RENDER_SEED, spp_per_pass=3)
+    whole = gpu_ctx.render(scene, info.camera, p, 10)
+    part = gpu_ctx.render(scene, info.camera, p, 4)
+    api.save_checkpoint(str(tmp_path / "ck.npz"), part, 4, util.RENDER_SEED)
+    rgb_sum, done, seed = api.load_checkpoint(str(tmp_path / "ck.npz"))
+    assert done == 4 and seed == util.RENDER_SEED
+    resumed = gpu_ctx.render_more(scene, info.camera, p, rgb_sum, done, 6)
+    assert resumed.tobytes() == whole.tobytes()
+    api.write_ppm(str(tmp_path / "out.ppm"), api.tonemap(resumed, 10))
+    data = open(str(tmp_path / "out.ppm"), "rb").read()
+    assert data.startswith(b"P6\n48 32\n255\n") and len(data) == len(b"P6\n48 32\n255\n") + 48 * 32 * 3
+    scene.close()
+
+
 def test_first_hit_edge_cases(gpu_ctx):
     _, info, blob, desc = util.build_scene("cornell_smoke")
     scene = gpu_ctx.upload(blob)
