@@ -196,11 +196,11 @@ def main():
             "reference_work": None if ref_work is None else dict(
                 ref_work, fp64_vector_frac=ref_work["flops"] * rate / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                 scene_read_gbs=ref_work["scene_bytes"] * rate / 1e9),
-            "kernel_ms": {"raygen": stats.raygen_ms, "extend_flat": stats.flat_ms, "extend_tree": stats.extend_ms, "bin": stats.bin_ms,
+            "kernel_ms": {"raygen": stats.raygen_ms, "extend_tree": stats.extend_ms, "shade_main": stats.shade_main_ms,
                           "accumulate": stats.accumulate_ms,
-                          "shade_lambertian": stats.shade_ms[0], "shade_metal": stats.shade_ms[1],
-                          "shade_dielectric": stats.shade_ms[2], "shade_diffuse_light": stats.shade_ms[3],
-                          "shade_isotropic": stats.shade_ms[4]},
+                          "shade_textured_lambertian": stats.shade_ms[0],
+                          "shade_textured_diffuse_light": stats.shade_ms[3],
+                          "shade_textured_isotropic": stats.shade_ms[4]},
         }
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(desc, info, render_seed, args.cpu_seconds)

@@ -149,11 +149,11 @@ typedef struct {
     uint64_t medium_tests;     /* ConstantMedium::hit calls (constant_medium.rs:25), not counted as rays */
     uint64_t passes;
     double seconds_render;     /* host wall clock around the device work */
-    /* HIP-event sums per kernel when profile = 1. extend_ms = the BVH traversal kernel (k_extend_tree);
-     * flat_ms = the lock-step test of the world's plain primitives and media; bin_ms = miss handling + queueing
-     * of hits by material; shade_ms[m] = material type m (Lambertian, Metal, Dielectric, DiffuseLight, Isotropic). */
-    double raygen_ms, extend_ms, shade_ms[5], accumulate_ms, flat_ms, bin_ms;
-    uint64_t raygen_launches, extend_launches, shade_launches, accumulate_launches, flat_launches, bin_launches;
+    /* HIP-event sums per kernel when profile = 1. extend_ms = closest-hit search (k_extend_tree); shade_main_ms =
+     * misses, shading of plain-colour materials and queueing of the rest (k_shade_main); shade_ms[m] = shading of hits
+     * on computed textures of material type m (Lambertian, Metal, Dielectric, DiffuseLight, Isotropic). */
+    double raygen_ms, extend_ms, shade_main_ms, shade_ms[5], accumulate_ms;
+    uint64_t raygen_launches, extend_launches, shade_main_launches, shade_launches, accumulate_launches;
     uint64_t extend_segments;  /* segments traced by the timed extend launches */
 } rt_stats;
 

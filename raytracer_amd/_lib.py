@@ -49,10 +49,10 @@ class rt_params(C.Structure):
 
 class rt_stats(C.Structure):
     _fields_ = [("camera_samples", C.c_uint64), ("ray_segments", C.c_uint64), ("medium_tests", C.c_uint64), ("passes", C.c_uint64),
-                ("seconds_render", C.c_double), ("raygen_ms", C.c_double), ("extend_ms", C.c_double), ("shade_ms", C.c_double * 5),
-                ("accumulate_ms", C.c_double), ("flat_ms", C.c_double), ("bin_ms", C.c_double),
-                ("raygen_launches", C.c_uint64), ("extend_launches", C.c_uint64), ("shade_launches", C.c_uint64),
-                ("accumulate_launches", C.c_uint64), ("flat_launches", C.c_uint64), ("bin_launches", C.c_uint64),
+                ("seconds_render", C.c_double), ("raygen_ms", C.c_double), ("extend_ms", C.c_double), ("shade_main_ms", C.c_double),
+                ("shade_ms", C.c_double * 5), ("accumulate_ms", C.c_double),
+                ("raygen_launches", C.c_uint64), ("extend_launches", C.c_uint64), ("shade_main_launches", C.c_uint64),
+                ("shade_launches", C.c_uint64), ("accumulate_launches", C.c_uint64),
                 ("extend_segments", C.c_uint64)]
 
 

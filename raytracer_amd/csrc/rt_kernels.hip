@@ -1040,8 +1040,7 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
                 if (sp.kind == 0) { stats->raygen_ms += ms; stats->raygen_launches++; }
                 else if (sp.kind == 1) { stats->extend_ms += ms; stats->extend_launches++; }
                 else if (sp.kind == 7) { stats->accumulate_ms += ms; stats->accumulate_launches++; }
-                else if (sp.kind == 8) { stats->flat_ms += ms; stats->flat_launches++; }
-                else if (sp.kind == 9) { stats->bin_ms += ms; stats->bin_launches++; }
+                else if (sp.kind == 9) { stats->shade_main_ms += ms; stats->shade_main_launches++; }
                 else { stats->shade_ms[sp.kind - 2] += ms; stats->shade_launches++; }
             }
             if (p->profile) stats->extend_segments += seg;

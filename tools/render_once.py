@@ -26,6 +26,6 @@ if a.width:
 p = api.params_from_info(info, spp_per_pass=a.spp, profile=1, **kw)
 st = api.rt_stats()
 img = ctx.render(sc, info.camera, p, a.spp * a.passes, stats=st)
-print("%s: %d samples, %d segments, %.3f s, %.1f Mrays/s; ms: raygen %.1f flat %.1f tree %.1f bin %.1f shade %s accumulate %.1f" %
+print("%s: %d samples, %d segments, %.3f s, %.1f Mrays/s; ms: raygen %.1f tree %.1f shade_main %.1f shade_textured %s accumulate %.1f" %
       (a.scene, st.camera_samples, st.ray_segments, st.seconds_render, st.ray_segments / st.seconds_render / 1e6, st.raygen_ms,
-       st.flat_ms, st.extend_ms, st.bin_ms, [round(x, 1) for x in st.shade_ms], st.accumulate_ms))
+       st.extend_ms, st.shade_main_ms, [round(x, 1) for x in st.shade_ms], st.accumulate_ms))
