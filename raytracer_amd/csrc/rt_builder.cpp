@@ -154,31 +154,39 @@ bool rt_builder::bounding_box(int h, double t0, double t1, AABB& out) const {
 // bounding_box(): a BvhNode's box and a primitive's own box are taken as they are, a box carried outward through
 // RotateY is really rotated (the reference's RotateY computes that box and drops it, hittable.rs:117-143), a list is
 // the union of its members, a medium is its boundary. false = unknown (treated as unbounded): a moving sphere, whose
-// extent depends on the shutter interval of the camera that will be used.
-bool rt_builder::world_bound(int h, AABB& out) const {
+// extent depends on the shutter interval of the camera that will be used - unless the caller passes `span`: then a
+// moving sphere is bounded over its own [time0, time1] (moving_sphere.rs:71-84), and `span` is narrowed to the ray
+// times for which that bound holds.
+bool rt_builder::world_bound(int h, AABB& out, TimeSpan* span) const {
     const ObjRec& o = objs[h];
     if (o.kind == OBJ_BVH) { out = o.box; return true; }
+    if (o.kind == OBJ_MSPHERE) {
+        if (!span) return false;
+        const double a = std::min(o.d[6], o.d[7]), b = std::max(o.d[6], o.d[7]);
+        span->lo = std::max(span->lo, a); span->hi = std::min(span->hi, b);
+        return bounding_box(h, a, b, out);
+    }
     if (o.kind == OBJ_SPHERE || o.kind == OBJ_XYRECT || o.kind == OBJ_XZRECT || o.kind == OBJ_YZRECT || o.kind == OBJ_BOX)
         return bounding_box(h, 0.0, 0.0, out);
-    if (o.kind == OBJ_MEDIUM) return world_bound(o.child, out);
+    if (o.kind == OBJ_MEDIUM) return world_bound(o.child, out, span);
     if (o.kind == OBJ_LIST) {
         if (o.members.empty()) return false;
         for (int i = 0; i < 3; ++i) { out.lo[i] = kInf; out.hi[i] = -kInf; }
         for (int m : o.members) {
             AABB c;
-            if (!world_bound(m, c)) return false;
+            if (!world_bound(m, c, span)) return false;
             for (int i = 0; i < 3; ++i) { out.lo[i] = std::min(out.lo[i], c.lo[i]); out.hi[i] = std::max(out.hi[i], c.hi[i]); }
         }
         return true;
     }
     if (o.kind == OBJ_TRANSLATE) {
-        if (!world_bound(o.child, out)) return false;
+        if (!world_bound(o.child, out, span)) return false;
         for (int i = 0; i < 3; ++i) { out.lo[i] += o.d[i]; out.hi[i] += o.d[i]; }
         return true;
     }
     if (o.kind == OBJ_ROTATE_Y) {
         AABB c;
-        if (!world_bound(o.child, c)) return false;
+        if (!world_bound(o.child, c, span)) return false;
         for (int i = 0; i < 3; ++i) { out.lo[i] = kInf; out.hi[i] = -kInf; }
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int k = 0; k < 2; ++k) {
             const double x = i ? c.hi[0] : c.lo[0], y = j ? c.hi[1] : c.lo[1], z = k ? c.hi[2] : c.lo[2];
@@ -603,7 +611,8 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     //  * an entry that is neither boundable nor testable in lock step (a nested list holding a moving sphere) is chained
     //    in front of the tree under the infinite box.
     // Bounds of anything seen through an instance carry a 1e-6 relative margin against the rounding of the frame change.
-    struct Item { int handle; bool bounded; AABB box; bool flatable; };
+    struct Item { int handle; bool bounded; AABB box; bool flatable; bool timed; };
+    TimeSpan shutter = {-kInf, kInf}; // ray times for which the bounds of all moving spheres put under the tree hold
     std::vector<Item> items;
     {
         std::vector<int> members;
@@ -618,7 +627,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
             if (o.kind == OBJ_BVH && o.exact_bounds && !(flags & RT_BLOB_FLAG_REFERENCE_TREE)) {
                 for (int sub : objs[o.child].members) {
                     Item it;
-                    it.handle = sub; it.flatable = flatable(sub);
+                    it.handle = sub; it.flatable = flatable(sub); it.timed = false;
                     it.bounded = bounding_box(sub, o.d[0], o.d[1], it.box);
                     if (!it.bounded) return fail(RT_ERR_PANIC, "No bounding box");
                     items.push_back(it);
@@ -628,7 +637,12 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
             Item it;
             it.handle = m;
             it.flatable = flatable(m);
-            it.bounded = world_bound(m, it.box);
+            // a moving sphere (possibly under instances, or as a medium's boundary) may go under the tree with the bound of
+            // its own time interval, because it also stays on the list used for rays outside that interval
+            TimeSpan span = {-kInf, kInf};
+            it.bounded = world_bound(m, it.box, it.flatable ? &span : nullptr);
+            it.timed = it.bounded && (span.lo > -kInf || span.hi < kInf);
+            if (it.timed && !(span.lo < span.hi)) { it.bounded = false; it.timed = false; }
             if (it.bounded) {
                 for (int c = 0; c < 3; ++c) {
                     if (!(std::fabs(it.box.lo[c]) < kInf) || !(std::fabs(it.box.hi[c]) < kInf)) { it.bounded = false; break; }
@@ -653,12 +667,20 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
             if (!huge) { in_tree[order[k]] = 1; acc = box_union(acc, it.box); }
         }
     }
-    std::vector<uint32_t> flat_refs, loose_refs;
+    std::vector<uint32_t> flat_refs, loose_refs, timed_refs;
     std::vector<SahItem> sah;
+    std::vector<char> handle_timed(objs.size(), 0);
     uint32_t need = 0;
     for (size_t i = 0; i < items.size(); ++i) {
         const Item& it = items[i];
         if (in_tree[i]) {
+            if (it.timed) {
+                TimeSpan span = {-kInf, kInf};
+                AABB unused;
+                world_bound(it.handle, unused, &span);
+                shutter.lo = std::max(shutter.lo, span.lo); shutter.hi = std::min(shutter.hi, span.hi);
+                handle_timed[(size_t)it.handle] = 1;
+            }
             SahItem si;
             si.obj = it.handle; si.box = it.box;
             for (int a = 0; a < 3; ++a) si.c[a] = 0.5 * (it.box.lo[a] + it.box.hi[a]);
@@ -686,9 +708,22 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
             root.node = 0; root.obj = -1;
         }
         uint32_t n = 0;
-        tree_ref = emit_ordered(f, tree, root, [&](int obj, uint32_t& ln) { return emit(f, obj, RT_NO_PARENT, 0, ln); }, n);
+        tree_ref = emit_ordered(f, tree, root, [&](int obj, uint32_t& ln) {
+            const uint32_t r = emit(f, obj, RT_NO_PARENT, 0, ln);
+            if (handle_timed[(size_t)obj] && r != RT_REF_NONE) timed_refs.push_back(r);
+            return r;
+        }, n);
         if (tree_ref == RT_REF_NONE) return error.empty() ? fail(RT_ERR_UNSUPPORTED, "empty scene") : RT_ERR_UNSUPPORTED;
         need = std::max(need, n);
+    }
+    uint32_t flat_any_ref = flat_ref;
+    if (!timed_refs.empty()) {
+        flat_any_ref = RT_MAKE_REF(RT_REF_LIST, f.list_entries.size());
+        for (uint32_t r : flat_refs) f.list_entries.push_back(r);
+        for (uint32_t r : timed_refs) f.list_entries.push_back(r);
+        f.list_entries.push_back(RT_REF_NONE);
+    } else {
+        shutter.lo = -kInf; shutter.hi = kInf;
     }
     for (size_t k = loose_refs.size(); k-- > 0;) { // T = { child 0: the entry, always entered; child 1: what was built so far }
         RtNode t = blank_node();
@@ -821,7 +856,8 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     blob.resize((blob.size() + 255u) & ~(size_t)255u);
     hd.magic = RT_BLOB_MAGIC; hd.version = RT_BLOB_VERSION;
     hd.total_bytes = blob.size();
-    hd.world = RT_REF_NONE;
+    hd.world_flat_any_time = flat_any_ref;
+    hd.shutter0 = shutter.lo; hd.shutter1 = shutter.hi;
     hd.world_flat = flat_ref;
     hd.world_tree = tree_ref;
     hd.n_media = (uint32_t)n_media;

@@ -87,7 +87,8 @@ struct rt_builder {
     bool valid_tex(int h) const;
     int add_obj(ObjRec o);
     bool bounding_box(int h, double t0, double t1, AABB& out) const;
-    bool world_bound(int h, AABB& out) const;
+    struct TimeSpan { double lo, hi; };
+    bool world_bound(int h, AABB& out, TimeSpan* span = nullptr) const;
     int build_bvh_node(std::vector<BNode>& tree, std::vector<int>& objects, const std::vector<double>& keys, size_t start,
                        size_t end, double t0, double t1);
     uint32_t emit(Flat& f, int h, int parent, uint32_t depth, uint32_t& need);

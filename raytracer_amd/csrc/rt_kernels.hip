@@ -671,8 +671,8 @@ void make_view(rt_scene* s) {
     v.perlin_vec = (const double*)(b + h.perlin_vec.offset);
     v.perlin_perm = (const int32_t*)(b + h.perlin_perm.offset);
     v.texels = (const uint8_t*)(b + h.texels.offset);
-    v.world = h.world;
-    v.world_flat = h.world_flat;
+    v.world = RT_REF_NONE;
+    v.world_flat = h.world_flat_any_time; // rays of any time (rt_trace_first_hit); a render narrows it, see rt_render_accumulate
     v.world_tree = h.world_tree;
     v.n_media = h.n_media;
     v.compat = 0;
@@ -837,7 +837,7 @@ static int upload_common(rt_context* ctx, const void* src, size_t nbytes, bool s
     if (e != hipSuccess) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_NO_DEVICE, "copy scene", e); }
     s->nbytes = nbytes;
     make_view(s);
-    s->has_flat = s->hdr.world_flat != RT_REF_NONE;
+    s->has_flat = s->hdr.world_flat_any_time != RT_REF_NONE;
     s->has_tree = s->hdr.world_tree != RT_REF_NONE;
     {
         std::vector<RtMaterial> mats(s->hdr.materials.count);
@@ -964,6 +964,9 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
 
     rt_scene local = *sc; // per-call compat bits ride in the by-value scene view
     local.view.compat = p->compat;
+    // every ray of this render has its time in the camera's shutter interval (camera.rs:62): when the bounds the
+    // compiler gave moving spheres in the tree hold for all of it, those spheres need no lock-step test
+    if (cam->time0 >= sc->hdr.shutter0 && cam->time1 <= sc->hdr.shutter1 && cam->time0 <= cam->time1) local.view.world_flat = sc->hdr.world_flat;
 
     const uint32_t stack_cap = sc->hdr.stack_need;
     // Persistent waves, one workgroup per CU: its LDS holds the traversal stacks and, in what is left, the first

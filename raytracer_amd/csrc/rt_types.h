@@ -10,7 +10,7 @@
 #include <stdint.h>
 
 #define RT_BLOB_MAGIC 0x31425452u /* "RTB1" little endian */
-#define RT_BLOB_VERSION 7u
+#define RT_BLOB_VERSION 8u
 
 // ---- tagged references -------------------------------------------------------------------------
 enum RtRefType : uint32_t {
@@ -117,7 +117,7 @@ struct RtSection { uint64_t offset; uint64_t count; };
 struct RtBlobHeader {
     uint32_t magic, version;
     uint64_t total_bytes;
-    uint32_t world;          // unused (NONE)
+    uint32_t world_flat_any_time; // LIST ref (or NONE): world_flat plus the moving spheres that sit in the tree under bounds valid for [shutter0, shutter1] only; used for rays whose time may lie outside that interval
     uint32_t world_flat;     // LIST ref (or NONE): the world entries (primitives or media, possibly under Translate/RotateY) that every lane tests in lock step: unbounded or huge ones
     uint32_t world_tree;     // NODE ref (or NONE): everything else of the world under one tree; walked per lane with a stack
     uint32_t n_media;        // number of ConstantMedium objects == free-flight draws per segment
@@ -125,6 +125,7 @@ struct RtBlobHeader {
     uint32_t max_chain;      // deepest instance nesting
     uint32_t flags;          // RT_BLOB_FLAG_*
     uint32_t n_objects;      // host handles issued (prim_id range)
+    double shutter0, shutter1; // ray times for which every bound in the tree holds (-inf, +inf when no moving sphere is bounded)
     RtSection nodes, spheres, sphere_meta, mspheres, msphere_meta, rects, rect_meta, boxes, box_meta,
         media, insts, list_entries, materials, textures, perlin_vec, perlin_perm, texels;
 };

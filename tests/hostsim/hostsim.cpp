@@ -63,8 +63,8 @@ bool view_of(const void* blob, size_t nbytes, DScene& v, RtBlobHeader& h) {
     v.perlin_vec = (const double*)(b + h.perlin_vec.offset);
     v.perlin_perm = (const int32_t*)(b + h.perlin_perm.offset);
     v.texels = (const uint8_t*)(b + h.texels.offset);
-    v.world = h.world;
-    v.world_flat = h.world_flat;
+    v.world = RT_REF_NONE;
+    v.world_flat = h.world_flat_any_time;
     v.world_tree = h.world_tree;
     v.n_media = h.n_media;
     v.compat = 0;
@@ -174,6 +174,7 @@ int hs_render(const void* blob, size_t nbytes, const rt_camera* cam, const rt_pa
     RtBlobHeader h;
     if (!view_of(blob, nbytes, sc, h)) return RT_ERR_INVALID;
     sc.compat = p->compat;
+    if (cam->time0 >= h.shutter0 && cam->time1 <= h.shutter1 && cam->time0 <= cam->time1) sc.world_flat = h.world_flat; // as rt_render_accumulate
     RtCameraDev cd;
     int rc = rt_camera_derive(cam, &cd);
     if (rc != RT_OK) return rc;
@@ -198,6 +199,7 @@ int hs_sample_radiance(const void* blob, size_t nbytes, const rt_camera* cam, co
     RtBlobHeader h;
     if (!view_of(blob, nbytes, sc, h)) return RT_ERR_INVALID;
     sc.compat = p->compat;
+    if (cam->time0 >= h.shutter0 && cam->time1 <= h.shutter1 && cam->time0 <= cam->time1) sc.world_flat = h.world_flat; // as rt_render_accumulate
     RtCameraDev cd;
     int rc = rt_camera_derive(cam, &cd);
     if (rc != RT_OK) return rc;
@@ -212,6 +214,7 @@ int hs_visit_stats(const void* blob, size_t nbytes, const rt_camera* cam, const 
     RtBlobHeader h;
     if (!view_of(blob, nbytes, sc, h)) return RT_ERR_INVALID;
     sc.compat = p->compat;
+    if (cam->time0 >= h.shutter0 && cam->time1 <= h.shutter1 && cam->time0 <= cam->time1) sc.world_flat = h.world_flat; // as rt_render_accumulate
     RtCameraDev cd;
     int rc = rt_camera_derive(cam, &cd);
     if (rc != RT_OK) return rc;

@@ -81,15 +81,16 @@ def test_unsupported_shapes_are_refused_at_compile_time():
     assert e.value.code == _lib.RT_ERR_UNSUPPORTED
 
 
-HEADER = struct.Struct("<IIQIIIIIIII")  # magic, version, total, world, world_flat, world_tree, n_media, stack_need, max_chain, flags, n_objects
+HEADER = struct.Struct("<IIQIIIIIIIIdd")  # magic, version, total, world_flat_any_time, world_flat, world_tree, n_media, stack_need, max_chain, flags, n_objects, shutter0, shutter1
 
 
 def header(blob):
-    magic, version, total, world, world_flat, world_tree, n_media, stack_need, max_chain, flags, n_objects = HEADER.unpack_from(blob, 0)
+    magic, version, total, world, world_flat, world_tree, n_media, stack_need, max_chain, flags, n_objects, shutter0, shutter1 = HEADER.unpack_from(blob, 0)
     secs = np.frombuffer(blob, dtype="<u8", count=17 * 2, offset=HEADER.size).reshape(17, 2)
     names = ["nodes", "spheres", "sphere_meta", "mspheres", "msphere_meta", "rects", "rect_meta", "boxes", "box_meta", "media",
              "insts", "list_entries", "materials", "textures", "perlin_vec", "perlin_perm", "texels"]
-    return dict(magic=magic, version=version, total=total, world=world, world_flat=world_flat, world_tree=world_tree, n_media=n_media, stack_need=stack_need,
+    return dict(magic=magic, version=version, total=total, world_flat_any_time=world, world_flat=world_flat, world_tree=world_tree, n_media=n_media, stack_need=stack_need,
+                shutter=(shutter0, shutter1),
                 max_chain=max_chain, flags=flags, n_objects=n_objects, sections={n: tuple(map(int, s)) for n, s in zip(names, secs)})
 
 
@@ -116,11 +117,12 @@ def test_blob_layout_of_the_book2_final_scene():
     h = header(blob)
     assert h["magic"] == 0x31425452 and h["total"] == len(blob) and len(blob) % 256 == 0
     s = h["sections"]
-    # The world list holds 11 entries (main.rs:576-688). Two are tested by every lane in lock step: the moving sphere
-    # (unbounded until the camera's shutter is known) and the r=5000 medium that contains the whole scene. The BvhNode
-    # of 400 boxes is dissolved; its boxes and the other 8 entries (7 primitives / media + the instanced cluster) form
-    # one tree of 408 leaves = 407 nodes; the cluster's own tree over 1000 spheres has 999.
-    assert s["nodes"][1] == 407 + 999
+    # The world list holds 11 entries (main.rs:576-688). One is tested by every lane in lock step: the r=5000 medium that
+    # contains the whole scene. The BvhNode of 400 boxes is dissolved; its boxes and the other 9 entries (8 primitives /
+    # media + the instanced cluster) form one tree of 409 leaves = 408 nodes; the cluster's own tree over 1000 spheres
+    # has 999. The moving sphere sits in the tree under the bound of its own time interval [0, 1] and, for rays of
+    # other times, on the second lock-step list as well.
+    assert s["nodes"][1] == 408 + 999
     assert s["boxes"][1] == 400 and s["mspheres"][1] == 1 and s["rects"][1] == 1
     assert s["spheres"][1] == 1000 + 5 + 2            # + the two medium boundaries (one is the shared r=70 sphere again)
     assert s["media"][1] == 2 == h["n_media"] and s["insts"][1] == 2 and h["max_chain"] == 2
@@ -129,8 +131,12 @@ def test_blob_layout_of_the_book2_final_scene():
     assert 2 <= h["stack_need"] <= 40
     entries = np.frombuffer(blob, dtype="<u4", count=s["list_entries"][1], offset=s["list_entries"][0])
     flat_first = h["world_flat"] & 0x03FFFFFF
-    flat = entries[flat_first:flat_first + 3]
-    assert (h["world_flat"] >> 28) == 8 and flat[2] == 0 and sorted(int(e) >> 28 for e in flat[:2]) == [3, 6]
+    flat = entries[flat_first:flat_first + 2]
+    assert (h["world_flat"] >> 28) == 8 and flat[1] == 0 and flat[0] >> 28 == 6
+    any_first = h["world_flat_any_time"] & 0x03FFFFFF
+    anyt = entries[any_first:any_first + 3]
+    assert (h["world_flat_any_time"] >> 28) == 8 and anyt[2] == 0 and sorted(int(e) >> 28 for e in anyt[:2]) == [3, 6]
+    assert h["shutter"] == (0.0, 1.0)
     # nodes are numbered breadth-first from the world's root
     nodes = nodes_of(blob, h)
     assert h["world_tree"] == (1 << 28) | 0

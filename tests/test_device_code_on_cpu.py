@@ -115,3 +115,29 @@ def test_reference_topology_trees_find_the_same_hits(name):
     want = osc.trace_first_hit(rays, xi)
     rep = util.first_hit_report(b, want)
     assert rep["prim_match"] == 1.0 and rep["t_bit_equal"] == 1.0, rep
+
+
+def test_moving_sphere_outside_the_interval_its_tree_bound_covers():
+    """A moving sphere at world level sits in the tree under the bound of its own [time0, time1]; rays of other times
+    (center() extrapolates, moving_sphere.rs:37-40) must still find it, through the lock-step list."""
+    import copy
+    _, info, blob, desc = util.build_scene("final_scene")
+    osc = ck.OracleScene(desc, share_bvh_axes=True)
+    # center(t) = (400, 400, 200) + (30, 0, 0) * t (main.rs:603-612): aim at where it is at t = 3, 5, -2 and at t = 0.5
+    times = np.array([3.0, 5.0, -2.0, 0.5])
+    origin = np.array([278.0, 278.0, -800.0])
+    targets = np.stack([400.0 + 30.0 * times, np.full(4, 400.0), np.full(4, 200.0)], axis=1)
+    rays = util.rays_from(np.broadcast_to(origin, (4, 3)), targets - origin, time=times)
+    xi = np.full((4, osc.n_media), 1e-12)             # free flight longer than the scene: no scatter on the way
+    want = osc.trace_first_hit(rays, xi)
+    got, _ = ck.hostsim_trace_first_hit(blob, rays, xi)
+    moving = [int(l.split()[1]) for l in desc.split(b"\n") if l.startswith(b"moving_sphere ")][0]
+    assert np.all(want["prim_id"] == moving) and np.array_equal(got["prim_id"], want["prim_id"])
+    assert np.array_equal(got["t"].view(np.uint64), want["t"].view(np.uint64))
+    # a render whose camera shutter leaves [0, 1]: every sample agrees with the oracle's
+    cam = copy.copy(info.camera)
+    cam.time0, cam.time1 = -1.0, 4.0
+    p = api.params_from_info(info, width=24, height=18, seed=util.RENDER_SEED)
+    a, _ = ck.hostsim_render(blob, cam, p, 2)
+    b, _ = osc.render(cam, p, 2, threads=4)
+    assert float((util.rel_err(a, b) > 1e-9).mean()) <= 0.002

@@ -90,6 +90,28 @@ def test_checkpoint_and_resume_is_bit_identical(gpu_ctx, tmp_path):
     scene.close()
 
 
+def test_camera_shutter_outside_the_moving_sphere_interval(gpu_ctx):
+    """final_scene's moving sphere is bounded in the tree for ray times in [0, 1]; a camera with a wider shutter must
+    take the lock-step list that still tests it at any time."""
+    import copy
+    _, info, blob, desc = util.build_scene("final_scene")
+    osc = ck.OracleScene(desc, share_bvh_axes=True)
+    scene = gpu_ctx.upload(blob)
+    cam = copy.copy(info.camera)
+    cam.time0, cam.time1 = -1.0, 4.0
+    p = api.params_from_info(info, width=64, height=48, seed=util.RENDER_SEED, spp_per_pass=4)
+    got = gpu_ctx.render(scene, cam, p, 4)
+    want, _ = osc.render(cam, p, 4)
+    assert float((util.rel_err(got, want) > 1e-9).mean()) <= 0.002
+    times = np.array([3.0, 5.0, -2.0, 0.5])
+    origin = np.array([278.0, 278.0, -800.0])
+    targets = np.stack([400.0 + 30.0 * times, np.full(4, 400.0), np.full(4, 200.0)], axis=1)
+    rays = util.rays_from(np.broadcast_to(origin, (4, 3)), targets - origin, time=times)
+    xi = np.full((4, osc.n_media), 1e-12)
+    assert np.array_equal(gpu_ctx.trace_first_hit(scene, rays, xi)["prim_id"], osc.trace_first_hit(rays, xi)["prim_id"])
+    scene.close()
+
+
 def test_first_hit_edge_cases(gpu_ctx):
     _, info, blob, desc = util.build_scene("cornell_smoke")
     scene = gpu_ctx.upload(blob)
