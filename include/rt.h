@@ -46,6 +46,11 @@ const char* rt_builder_last_error(const rt_builder*);
  * it, a BvhNode whose boxes all bound their contents is compiled into a surface-area-heuristic tree over the same
  * objects: closest hits are the same, fewer boxes are tested. Trees with a box that does not bound its contents
  * (anything over the reference's RotateY) always keep the reference's topology and test order.
+ * bit 2 = rays may carry any time. A BvhNode over moving spheres has boxes for its own [time0, time1] only (bvh.rs:15,
+ * moving_sphere.rs:71-84); by default such a node is rebuilt like any other and the compiled scene is valid for ray
+ * times inside that interval - a render with a wider camera shutter, or a first-hit query outside it, returns
+ * RT_ERR_UNSUPPORTED. With the bit set such nodes are replayed in the reference's form (same culling, slower) and
+ * any time is accepted. Set before creating moving spheres.
  * Default 0. */
 int rt_builder_set_flags(rt_builder*, uint32_t flags);
 

@@ -645,8 +645,9 @@ struct RotateY : Hittable {
     HittablePtr ptr; double sin_theta, cos_theta; bool hasbox; AABB bbox; bool book_rotate_bbox = false;
     RotateY(HittablePtr p, double angle, bool book_bbox) : ptr(p) { // :104-144
         double radians = degrees_to_radians(angle);
-        sin_theta = std::sin(radians);
-        cos_theta = std::cos(radians);
+        // glibc's sin()/cos() and sincos() may differ in the last bit; compilers merge the two calls or not as they
+        // please, so the pair is asked for explicitly (the product's builder does the same)
+        ::sincos(radians, &sin_theta, &cos_theta);
         hasbox = ptr->bounding_box(0.0, 1.0, bbox);
         Point3 min(INFINITY_, INFINITY_, INFINITY_), max(-INFINITY_, -INFINITY_, -INFINITY_);
         for (int i = 0; i < 2; ++i)

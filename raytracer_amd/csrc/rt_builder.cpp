@@ -198,6 +198,29 @@ bool rt_builder::world_bound(int h, AABB& out, TimeSpan* span) const {
     return false;
 }
 
+bool rt_builder::has_moving(int h) const {
+    const ObjRec& o = objs[h];
+    switch (o.kind) {
+    case OBJ_MSPHERE: return true;
+    case OBJ_TRANSLATE: case OBJ_ROTATE_Y: case OBJ_MEDIUM: return has_moving(o.child);
+    case OBJ_LIST:
+        for (int m : o.members) if (has_moving(m)) return true;
+        return false;
+    case OBJ_BVH:
+        for (int m : objs[o.child].members) if (has_moving(m)) return true;
+        return false;
+    default: return false;
+    }
+}
+// A BvhNode that is rebuilt (its own leaf boxes then cull) is right only for the ray times its boxes were made for.
+void rt_builder::limit_time(const ObjRec& bvh) {
+    bool moving = false;
+    for (int m : objs[bvh.child].members) moving = moving || has_moving(m);
+    if (!moving) return;
+    valid_lo = std::max(valid_lo, std::min(bvh.d[0], bvh.d[1]));
+    valid_hi = std::min(valid_hi, std::max(bvh.d[0], bvh.d[1]));
+}
+
 // BvhNode::new (bvh.rs:15-66). Returns the index of the node created in `tree`, or -1 after fail().
 int rt_builder::build_bvh_node(std::vector<BNode>& tree, std::vector<int>& objects, const std::vector<double>& keys,
                                size_t start, size_t end, double t0, double t1) {
@@ -487,6 +510,7 @@ static uint32_t emit_ordered(rt_builder::Flat& f, const std::vector<TNode>& tree
 
 uint32_t rt_builder::emit_bvh(Flat& f, const ObjRec& o, int parent, uint32_t depth, uint32_t& need) {
     if (o.exact_bounds) {
+        limit_time(o);
         std::vector<TNode> tree;
         Kid root;
         if (flags & RT_BLOB_FLAG_REFERENCE_TREE) {
@@ -555,6 +579,7 @@ uint32_t rt_builder::emit_replay(Flat& f, const ObjRec& o, int node, int parent,
     const BNode& bn = o.tree[(size_t)node];
     const uint32_t me = (uint32_t)f.nodes.size();
     f.nodes.push_back(blank_node());
+    f.nodes[me].pad[0] = RT_NODE_ORDERED;
     uint32_t n0 = 0, n1 = 0, c0, c1 = RT_REF_NONE;
     if (bn.left_node >= 0) c0 = emit_replay(f, o, bn.left_node, parent, depth, n0);
     else c0 = emit(f, bn.left_obj, parent, depth, n0);
@@ -596,6 +621,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     if (!blob_out || !nbytes) return fail(RT_ERR_INVALID, "null output");
     if (!valid_obj(world)) return fail(RT_ERR_INVALID, "world handle %d is not a hittable", world);
     Flat f;
+    valid_lo = -kInf; valid_hi = kInf;
     // world.hit (hittable_list.rs:40-53) returns the closest hit over the world's entries, and that does not depend on
     // the order the entries are tested in or on which of them are skipped because the ray misses their bounds (only
     // exact ties do). So the compiler is free to arrange the entries for the hardware:
@@ -611,25 +637,59 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     //  * an entry that is neither boundable nor testable in lock step (a nested list holding a moving sphere) is chained
     //    in front of the tree under the infinite box.
     // Bounds of anything seen through an instance carry a 1e-6 relative margin against the rounding of the frame change.
+    //
+    // All of that holds for entries whose hit(r, t_min, t_max) returns their nearest hit below t_max whatever t_max is
+    // ("monotone"). A BvhNode with a box that does not bound its contents is not: what it finds depends on the t_max it is
+    // entered with (bvh.rs:113 culls against it), hence on which entries of the list were tested before it
+    // (hittable_list.rs:45-51). Such an entry is a barrier: the entries before it, the entry, and the entries after it
+    // are kept in that order (nodes flagged as ordered), and only the runs between barriers are rearranged as above,
+    // without a lock-step list.
+    std::function<bool(int)> monotone = [&](int h) -> bool {
+        const ObjRec& o = objs[h];
+        switch (o.kind) {
+        case OBJ_TRANSLATE: case OBJ_ROTATE_Y: return monotone(o.child);
+        case OBJ_LIST:
+            for (int m : o.members) if (!monotone(m)) return false;
+            return true;
+        case OBJ_BVH:
+            if (!o.exact_bounds) return false;
+            for (int m : objs[o.child].members) if (!monotone(m)) return false;
+            return true;
+        default: return true;
+        }
+    };
     struct Item { int handle; bool bounded; AABB box; bool flatable; bool timed; };
+    struct Run { uint32_t ref = RT_REF_NONE; AABB box = kEmptyBox; bool all = false; }; // all: every ray must enter it
     TimeSpan shutter = {-kInf, kInf}; // ray times for which the bounds of all moving spheres put under the tree hold
-    std::vector<Item> items;
-    {
-        std::vector<int> members;
-        if (objs[world].kind == OBJ_LIST) members = objs[world].members; else members.push_back(world);
-        auto flatable = [&](int h) { // a primitive or medium under at most RT_MAX_CHAIN instances
-            uint32_t chain = 0;
-            while (objs[h].kind == OBJ_TRANSLATE || objs[h].kind == OBJ_ROTATE_Y) { h = objs[h].child; ++chain; }
-            return objs[h].kind != OBJ_BVH && objs[h].kind != OBJ_LIST && chain <= RT_MAX_CHAIN;
-        };
+    std::vector<uint32_t> flat_refs, timed_refs;
+    uint32_t need = 0;
+    int run_rc = RT_OK;
+    auto flatable = [&](int h) { // a primitive or medium under at most RT_MAX_CHAIN instances
+        uint32_t chain = 0;
+        while (objs[h].kind == OBJ_TRANSLATE || objs[h].kind == OBJ_ROTATE_Y) { h = objs[h].child; ++chain; }
+        return objs[h].kind != OBJ_BVH && objs[h].kind != OBJ_LIST && chain <= RT_MAX_CHAIN;
+    };
+    auto add_margin = [&](AABB& box) -> bool { // false: not finite
+        for (int c = 0; c < 3; ++c) {
+            if (!(std::fabs(box.lo[c]) < kInf) || !(std::fabs(box.hi[c]) < kInf)) return false;
+            const double mg = 1e-6 * std::max(std::max(std::fabs(box.lo[c]), std::fabs(box.hi[c])), box.hi[c] - box.lo[c]) + 1e-9;
+            box.lo[c] -= mg; box.hi[c] += mg;
+        }
+        return true;
+    };
+    // One run of monotone entries -> a tree (and, where allowed, additions to the lock-step list).
+    auto build_run = [&](const std::vector<int>& members, bool lock_step) -> Run {
+        Run out;
+        std::vector<Item> items;
         for (int m : members) {
             const ObjRec& o = objs[m];
             if (o.kind == OBJ_BVH && o.exact_bounds && !(flags & RT_BLOB_FLAG_REFERENCE_TREE)) {
+                limit_time(o);
                 for (int sub : objs[o.child].members) {
                     Item it;
                     it.handle = sub; it.flatable = flatable(sub); it.timed = false;
                     it.bounded = bounding_box(sub, o.d[0], o.d[1], it.box);
-                    if (!it.bounded) return fail(RT_ERR_PANIC, "No bounding box");
+                    if (!it.bounded) { run_rc = fail(RT_ERR_PANIC, "No bounding box"); return out; }
                     items.push_back(it);
                 }
                 continue;
@@ -640,81 +700,129 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
             // a moving sphere (possibly under instances, or as a medium's boundary) may go under the tree with the bound of
             // its own time interval, because it also stays on the list used for rays outside that interval
             TimeSpan span = {-kInf, kInf};
-            it.bounded = world_bound(m, it.box, it.flatable ? &span : nullptr);
+            it.bounded = world_bound(m, it.box, lock_step && it.flatable ? &span : nullptr);
             it.timed = it.bounded && (span.lo > -kInf || span.hi < kInf);
             if (it.timed && !(span.lo < span.hi)) { it.bounded = false; it.timed = false; }
-            if (it.bounded) {
-                for (int c = 0; c < 3; ++c) {
-                    if (!(std::fabs(it.box.lo[c]) < kInf) || !(std::fabs(it.box.hi[c]) < kInf)) { it.bounded = false; break; }
-                    const double mg = 1e-6 * std::max(std::max(std::fabs(it.box.lo[c]), std::fabs(it.box.hi[c])), it.box.hi[c] - it.box.lo[c]) + 1e-9;
-                    it.box.lo[c] -= mg; it.box.hi[c] += mg;
-                }
-            }
+            if (it.bounded && !add_margin(it.box)) it.bounded = false;
             items.push_back(it);
         }
-    }
-    if (items.empty()) return fail(RT_ERR_UNSUPPORTED, "empty scene");
-    // huge = at least as large as everything smaller than it put together: peel such items off, largest first
-    std::vector<char> in_tree(items.size(), 0);
-    {
-        std::vector<size_t> order;
-        for (size_t i = 0; i < items.size(); ++i) if (items[i].bounded) order.push_back(i);
-        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return half_area(items[a].box) < half_area(items[b].box); });
-        AABB acc = kEmptyBox;
-        for (size_t k = 0; k < order.size(); ++k) { // ascending: acc = union of everything smaller
-            const Item& it = items[order[k]];
-            const bool huge = it.flatable && k > 0 && half_area(it.box) >= 4.0 * half_area(acc);
-            if (!huge) { in_tree[order[k]] = 1; acc = box_union(acc, it.box); }
-        }
-    }
-    std::vector<uint32_t> flat_refs, loose_refs, timed_refs;
-    std::vector<SahItem> sah;
-    std::vector<char> handle_timed(objs.size(), 0);
-    uint32_t need = 0;
-    for (size_t i = 0; i < items.size(); ++i) {
-        const Item& it = items[i];
-        if (in_tree[i]) {
-            if (it.timed) {
-                TimeSpan span = {-kInf, kInf};
-                AABB unused;
-                world_bound(it.handle, unused, &span);
-                shutter.lo = std::max(shutter.lo, span.lo); shutter.hi = std::min(shutter.hi, span.hi);
-                handle_timed[(size_t)it.handle] = 1;
+        if (items.empty()) return out;
+        // huge = at least as large as everything smaller than it put together: peel such items off, largest first
+        std::vector<char> in_tree(items.size(), 0);
+        {
+            std::vector<size_t> order;
+            for (size_t i = 0; i < items.size(); ++i) if (items[i].bounded) order.push_back(i);
+            std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return half_area(items[a].box) < half_area(items[b].box); });
+            AABB acc = kEmptyBox;
+            for (size_t k = 0; k < order.size(); ++k) { // ascending: acc = union of everything smaller
+                const Item& it = items[order[k]];
+                const bool huge = lock_step && it.flatable && k > 0 && half_area(it.box) >= 4.0 * half_area(acc);
+                if (!huge) { in_tree[order[k]] = 1; acc = box_union(acc, it.box); }
             }
-            SahItem si;
-            si.obj = it.handle; si.box = it.box;
-            for (int a = 0; a < 3; ++a) si.c[a] = 0.5 * (it.box.lo[a] + it.box.hi[a]);
-            sah.push_back(si);
-            continue;
         }
-        uint32_t n = 0;
-        const uint32_t r = emit(f, it.handle, RT_NO_PARENT, 0, n);
-        if (r == RT_REF_NONE) return error.empty() ? fail(RT_ERR_UNSUPPORTED, "empty scene") : RT_ERR_UNSUPPORTED;
-        if (it.flatable) flat_refs.push_back(r);
-        else { loose_refs.push_back(r); need = std::max(need, n); }
-    }
+        std::vector<uint32_t> loose_refs;
+        std::vector<SahItem> sah;
+        std::vector<char> handle_timed(objs.size(), 0);
+        for (size_t i = 0; i < items.size(); ++i) {
+            const Item& it = items[i];
+            if (in_tree[i]) {
+                if (it.timed) {
+                    TimeSpan span = {-kInf, kInf};
+                    AABB unused;
+                    world_bound(it.handle, unused, &span);
+                    shutter.lo = std::max(shutter.lo, span.lo); shutter.hi = std::min(shutter.hi, span.hi);
+                    handle_timed[(size_t)it.handle] = 1;
+                }
+                SahItem si;
+                si.obj = it.handle; si.box = it.box;
+                for (int a = 0; a < 3; ++a) si.c[a] = 0.5 * (it.box.lo[a] + it.box.hi[a]);
+                sah.push_back(si);
+                continue;
+            }
+            uint32_t n = 0;
+            const uint32_t r = emit(f, it.handle, RT_NO_PARENT, 0, n);
+            if (r == RT_REF_NONE) { run_rc = error.empty() ? fail(RT_ERR_UNSUPPORTED, "empty scene") : RT_ERR_UNSUPPORTED; return out; }
+            if (lock_step && it.flatable) flat_refs.push_back(r);
+            else { loose_refs.push_back(r); need = std::max(need, n); }
+        }
+        if (!sah.empty()) {
+            std::vector<TNode> tree;
+            Kid root = build_sah(tree, sah, 0, sah.size(), 0);
+            if (root.node < 0) { // a single item still needs a node to carry its box
+                tree.push_back(TNode());
+                tree[0].kid[0] = root;
+                root.node = 0; root.obj = -1;
+            }
+            uint32_t n = 0;
+            out.ref = emit_ordered(f, tree, root, [&](int obj, uint32_t& ln) {
+                const uint32_t r = emit(f, obj, RT_NO_PARENT, 0, ln);
+                if (handle_timed[(size_t)obj] && r != RT_REF_NONE) timed_refs.push_back(r);
+                return r;
+            }, n);
+            if (out.ref == RT_REF_NONE) { run_rc = error.empty() ? fail(RT_ERR_UNSUPPORTED, "empty scene") : RT_ERR_UNSUPPORTED; return out; }
+            out.box = root.box;
+            need = std::max(need, n);
+        }
+        for (size_t k = loose_refs.size(); k-- > 0;) { // T = { child 0: the entry, always entered; child 1: what was built so far }
+            RtNode t = blank_node();
+            set_box_all(t.lo0, t.hi0);
+            t.c0 = loose_refs[k];
+            if (out.ref != RT_REF_NONE) { set_box_all(t.lo1, t.hi1); t.c1 = out.ref; }
+            f.nodes.push_back(t);
+            out.ref = RT_MAKE_REF(RT_REF_NODE, f.nodes.size() - 1);
+            out.all = true;
+            need += 1u;
+        }
+        return out;
+    };
+    std::vector<int> world_members;
+    if (objs[world].kind == OBJ_LIST) world_members = objs[world].members; else world_members.push_back(world);
+    if (world_members.empty()) return fail(RT_ERR_UNSUPPORTED, "empty scene");
+    bool all_monotone = true;
+    for (int m : world_members) all_monotone = all_monotone && monotone(m);
     uint32_t flat_ref = RT_REF_NONE, tree_ref = RT_REF_NONE;
+    if (all_monotone) {
+        const Run r = build_run(world_members, true);
+        if (run_rc != RT_OK) return run_rc;
+        tree_ref = r.ref;
+    } else {
+        std::vector<Run> sequence;
+        std::vector<int> run;
+        auto flush = [&]() {
+            if (run.empty() || run_rc != RT_OK) return;
+            sequence.push_back(build_run(run, false));
+            run.clear();
+        };
+        for (int m : world_members) {
+            if (monotone(m)) { run.push_back(m); continue; }
+            flush();
+            if (run_rc != RT_OK) return run_rc;
+            Run barrier;
+            uint32_t n = 0;
+            barrier.ref = emit(f, m, RT_NO_PARENT, 0, n);
+            if (barrier.ref == RT_REF_NONE) return error.empty() ? fail(RT_ERR_UNSUPPORTED, "empty scene") : RT_ERR_UNSUPPORTED;
+            need = std::max(need, n);
+            barrier.all = !(world_bound(m, barrier.box) && add_margin(barrier.box));
+            sequence.push_back(barrier);
+        }
+        flush();
+        if (run_rc != RT_OK) return run_rc;
+        for (size_t k = sequence.size(); k-- > 0;) { // { child 0: part k, child 1: parts k+1.. under the infinite box }, in that order
+            if (sequence[k].ref == RT_REF_NONE) continue;
+            RtNode t = blank_node();
+            if (sequence[k].all) set_box_all(t.lo0, t.hi0); else set_box(t.lo0, t.hi0, sequence[k].box);
+            t.c0 = sequence[k].ref;
+            if (tree_ref != RT_REF_NONE) { set_box_all(t.lo1, t.hi1); t.c1 = tree_ref; }
+            t.pad[0] = RT_NODE_ORDERED;
+            f.nodes.push_back(t);
+            tree_ref = RT_MAKE_REF(RT_REF_NODE, f.nodes.size() - 1);
+            need += 1u;
+        }
+    }
     if (!flat_refs.empty()) {
         flat_ref = RT_MAKE_REF(RT_REF_LIST, f.list_entries.size());
         for (uint32_t r : flat_refs) f.list_entries.push_back(r);
         f.list_entries.push_back(RT_REF_NONE);
-    }
-    if (!sah.empty()) {
-        std::vector<TNode> tree;
-        Kid root = build_sah(tree, sah, 0, sah.size(), 0);
-        if (root.node < 0) { // a single item still needs a node to carry its box
-            tree.push_back(TNode());
-            tree[0].kid[0] = root;
-            root.node = 0; root.obj = -1;
-        }
-        uint32_t n = 0;
-        tree_ref = emit_ordered(f, tree, root, [&](int obj, uint32_t& ln) {
-            const uint32_t r = emit(f, obj, RT_NO_PARENT, 0, ln);
-            if (handle_timed[(size_t)obj] && r != RT_REF_NONE) timed_refs.push_back(r);
-            return r;
-        }, n);
-        if (tree_ref == RT_REF_NONE) return error.empty() ? fail(RT_ERR_UNSUPPORTED, "empty scene") : RT_ERR_UNSUPPORTED;
-        need = std::max(need, n);
     }
     uint32_t flat_any_ref = flat_ref;
     if (!timed_refs.empty()) {
@@ -725,15 +833,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     } else {
         shutter.lo = -kInf; shutter.hi = kInf;
     }
-    for (size_t k = loose_refs.size(); k-- > 0;) { // T = { child 0: the entry, always entered; child 1: what was built so far }
-        RtNode t = blank_node();
-        set_box_all(t.lo0, t.hi0);
-        t.c0 = loose_refs[k];
-        if (tree_ref != RT_REF_NONE) { set_box_all(t.lo1, t.hi1); t.c1 = tree_ref; }
-        f.nodes.push_back(t);
-        tree_ref = RT_MAKE_REF(RT_REF_NODE, f.nodes.size() - 1);
-        need += 1u;
-    }
+    if (flat_ref == RT_REF_NONE && tree_ref == RT_REF_NONE) return fail(RT_ERR_UNSUPPORTED, "empty scene");
     // Node numbering: breadth-first from the world's root for the first kBreadthFirst records - the traversal kernel keeps
     // a prefix of the node array in LDS, and these are the records nearest the root, which every ray visits - then
     // depth-first (a node followed by its child-0 subtree), which keeps a deep descent within few cache lines.
@@ -858,6 +958,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     hd.total_bytes = blob.size();
     hd.world_flat_any_time = flat_any_ref;
     hd.shutter0 = shutter.lo; hd.shutter1 = shutter.hi;
+    hd.valid0 = valid_lo; hd.valid1 = valid_hi;
     hd.world_flat = flat_ref;
     hd.world_tree = tree_ref;
     hd.n_media = (uint32_t)n_media;
@@ -1003,6 +1104,9 @@ int rt_moving_sphere(rt_builder* b, const double c0[3], const double c1[3], doub
     if (!b) return RT_ERR_INVALID;
     if (!c0 || !c1 || !b->valid_mat(mat)) return b->fail(RT_ERR_INVALID, "moving_sphere: bad argument");
     ObjRec o; o.kind = OBJ_MSPHERE; o.mat = mat;
+    // its box holds for the interval a BvhNode was given, not for every ray time: under RT_BLOB_FLAG_ANY_TIME that
+    // counts as a box that does not bound its contents
+    o.exact_bounds = !(b->flags & RT_BLOB_FLAG_ANY_TIME);
     for (int i = 0; i < 3; ++i) { o.d[i] = c0[i]; o.d[3 + i] = c1[i]; }
     o.d[6] = time0; o.d[7] = time1; o.d[8] = radius;
     int id = b->add_obj(o);
@@ -1052,7 +1156,10 @@ int rt_rotate_y(rt_builder* b, int child, double angle) {
     ObjRec o; o.kind = OBJ_ROTATE_Y; o.child = child;
     o.exact_bounds = (b->flags & RT_BLOB_FLAG_BOOK_BBOX) != 0 && b->objs[child].exact_bounds;
     const double radians = angle * RT_PI / 180.0; // rtweekend.rs:5-7
-    o.d[0] = std::sin(radians); o.d[1] = std::cos(radians); o.d[2] = 0.0;
+    // (sincos, not sin and cos: glibc's two entry points may differ in the last bit, and whether a compiler merges
+    // the two calls is its own business - the test oracle asks for the pair the same way)
+    ::sincos(radians, &o.d[0], &o.d[1]);
+    o.d[2] = 0.0;
     // RotateY::new (hittable.rs:104-144): bbox = the child's box at times (0,1); the rotated min/max
     // computed at :117-141 are dropped unless the book-behaviour flag asks for them.
     for (int i = 0; i < 3; ++i) o.box.lo[i] = o.box.hi[i] = 0.0;

@@ -80,6 +80,9 @@ struct rt_builder {
     std::string log;
     std::string axis_log; // split axes of the BVH being built, one digit per BvhNode::new call
     std::string error;
+    double valid_lo = -std::numeric_limits<double>::infinity(), valid_hi = std::numeric_limits<double>::infinity(); // set by compile()
+    bool has_moving(int h) const; // a moving sphere somewhere below h
+    void limit_time(const ObjRec& bvh);
 
     int fail(int code, const char* fmt, ...);
     bool valid_obj(int h) const;

@@ -119,7 +119,7 @@ RT_HD RtNode rt_load_node(const RtNode* p) {
     n.lo1[0] = __uint_as_float(b.z); n.lo1[1] = __uint_as_float(b.w); n.lo1[2] = __uint_as_float(c.x);
     n.hi1[0] = __uint_as_float(c.y); n.hi1[1] = __uint_as_float(c.z); n.hi1[2] = __uint_as_float(c.w);
     n.c0 = d.x; n.c1 = d.y;
-    n.pad[0] = 0u; n.pad[1] = 0u;
+    n.pad[0] = d.z; n.pad[1] = 0u;
     return n;
 #else
     return *p;
@@ -359,8 +359,8 @@ struct RtTrav {
 // when, or in which order, so such trees are stored with real boxes on both children and walked nearest first.
 // Where a box does not bound its contents (RotateY keeps its child's unrotated box, hittable.rs:115-143) what
 // the reference finds depends on exactly which boxes it tests and with which t_max, so those trees are encoded
-// to replay it: child 1 of a node carries the infinite box (entered at t_min, so never before child 0) and leads
-// to a one-child node holding the real right box, which is therefore tested only after the left subtree is done.
+// to replay it: the node is flagged ordered (child 0 first, always), child 1 carries the infinite box and leads to a
+// one-child node holding the real right box, which is therefore tested only after the left subtree is done.
 // Nodes: RtNode load(uint32_t index) - where node records come from (global memory, or a kernel's cached copy).
 struct GlobalNodes {
     const RtNode* nodes;
@@ -374,7 +374,7 @@ RT_HD void rt_trav_node_step(const Nodes& nodes, RtTrav& s, Stack& st, double t_
     const bool h0 = rt_aabb_hit(n.lo0, n.hi0, s.r, s.slab, t_min, s.best.t, e0);
     const bool h1 = rt_aabb_hit(n.lo1, n.hi1, s.r, s.slab, t_min, s.best.t, e1);
     if (h0 && h1) {
-        const bool swap = e1 < e0;
+        const bool swap = e1 < e0 && n.pad[0] == 0u;
         st.push(swap ? n.c0 : n.c1);
         s.cur = swap ? n.c1 : n.c0;
     } else if (h0 || h1) {

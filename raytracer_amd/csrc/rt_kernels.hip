@@ -117,7 +117,7 @@ struct CachedNodes {
         n.lo1[0] = __uint_as_float(b.z); n.lo1[1] = __uint_as_float(b.w); n.lo1[2] = __uint_as_float(c.x);
         n.hi1[0] = __uint_as_float(c.y); n.hi1[1] = __uint_as_float(c.z); n.hi1[2] = __uint_as_float(c.w);
         n.c0 = d.x; n.c1 = d.y;
-        n.pad[0] = 0u; n.pad[1] = 0u;
+        n.pad[0] = d.z; n.pad[1] = 0u;
         return n;
     }
 };
@@ -880,6 +880,9 @@ int rt_trace_first_hit(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays
     if (!ctx) return RT_ERR_INVALID;
     if (!sc || (!rays && n) || (!out && n) || n > 0x7FFFFFFFu) return ctx_fail(ctx, RT_ERR_INVALID, "trace_first_hit: bad argument");
     if (n == 0) return RT_OK;
+    for (size_t i = 0; i < n; ++i)
+        if (rays[i].time < sc->hdr.valid0 || rays[i].time > sc->hdr.valid1)
+            return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "trace_first_hit: a ray's time lies outside the interval the scene's BvhNodes over moving spheres were built for (compile with builder flag 4 for any time)");
     RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     rt_ray_d* d_rays = nullptr;
     rt_hit* d_out = nullptr;
@@ -937,6 +940,8 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
     RtCameraDev cd;
     int rc = rt_camera_derive(cam, &cd);
     if (rc != RT_OK) return ctx_fail(ctx, rc, "camera: the reference would panic on these arguments");
+    if (cam->time0 < sc->hdr.valid0 || cam->time1 > sc->hdr.valid1)
+        return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "render: the camera's shutter leaves the interval the scene's BvhNodes over moving spheres were built for (compile with builder flag 4 for any time)");
     RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     rc = ensure_pixmap(ctx, p);
     if (rc != RT_OK) return rc;

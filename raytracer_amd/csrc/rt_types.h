@@ -10,7 +10,7 @@
 #include <stdint.h>
 
 #define RT_BLOB_MAGIC 0x31425452u /* "RTB1" little endian */
-#define RT_BLOB_VERSION 8u
+#define RT_BLOB_VERSION 9u
 
 // ---- tagged references -------------------------------------------------------------------------
 enum RtRefType : uint32_t {
@@ -44,13 +44,14 @@ enum RtRefType : uint32_t {
 // nearer child can be entered first. A child ref is another node or the object the reference would store in that
 // Arc (bvh.rs:8-12). An absent child has ref NONE and the empty box (lo = +inf, hi = -inf), which no ray hits; a
 // child that must be entered without a box test (an object directly under a reference-order node, whose hit() has
-// no box of its own) has the infinite box. Nodes of one tree are stored in depth-first pre-order.
+// no box of its own) has the infinite box. The nearer child is entered first unless the node is flagged ordered. Nodes of one tree are stored in depth-first pre-order.
 struct RtNode {
     float lo0[3], hi0[3]; // child 0
     float lo1[3], hi1[3]; // child 1
     uint32_t c0, c1;
-    uint32_t pad[2];
+    uint32_t pad[2];      // pad[0]: RT_NODE_* flags
 };
+#define RT_NODE_ORDERED 1u /* child 0 is entered (and finished) before child 1 whatever their distances */
 
 // Common per-primitive bookkeeping, one per geometry record (same index).
 struct RtMeta {
@@ -125,12 +126,14 @@ struct RtBlobHeader {
     uint32_t max_chain;      // deepest instance nesting
     uint32_t flags;          // RT_BLOB_FLAG_*
     uint32_t n_objects;      // host handles issued (prim_id range)
-    double shutter0, shutter1; // ray times for which every bound in the tree holds (-inf, +inf when no moving sphere is bounded)
+    double shutter0, shutter1; // ray times for which world_flat suffices: the moving spheres listed only in world_flat_any_time keep to their tree bounds (-inf, +inf when there are none)
+    double valid0, valid1;     // ray times the blob may be traced with at all: those the BvhNodes holding moving spheres were built for (bvh.rs:15, time0..time1); (-inf, +inf) without such nodes or with RT_BLOB_FLAG_ANY_TIME
     RtSection nodes, spheres, sphere_meta, mspheres, msphere_meta, rects, rect_meta, boxes, box_meta,
         media, insts, list_entries, materials, textures, perlin_vec, perlin_perm, texels;
 };
 #define RT_BLOB_FLAG_BOOK_BBOX 1u      /* RotateY stores its rotated box (book behaviour) instead of the child's */
 #define RT_BLOB_FLAG_REFERENCE_TREE 2u /* every BvhNode keeps the reference's topology (random-axis median split) */
+#define RT_BLOB_FLAG_ANY_TIME 4u       /* rays may carry any time: a BvhNode over moving spheres is replayed in the reference's form instead of being rebuilt */
 
 // ---- render-time records -------------------------------------------------------------------------
 // Camera in the derived form the reference's Camera struct holds (camera.rs:7-18).

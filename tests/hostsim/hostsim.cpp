@@ -92,6 +92,8 @@ int hs_trace_first_hit(const void* blob, size_t nbytes, const rt_ray_d* rays, si
     if (!view_of(blob, nbytes, sc, h)) return RT_ERR_INVALID;
     sc.compat = compat;
     uint32_t high = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (rays[i].time < h.valid0 || rays[i].time > h.valid1) return RT_ERR_UNSUPPORTED; // as rt_trace_first_hit
     for (size_t i = 0; i < n; ++i) {
         Ray r;
         r.o = v3(rays[i].ox, rays[i].oy, rays[i].oz); r.d = v3(rays[i].dx, rays[i].dy, rays[i].dz); r.tm = rays[i].time;
@@ -174,6 +176,7 @@ int hs_render(const void* blob, size_t nbytes, const rt_camera* cam, const rt_pa
     RtBlobHeader h;
     if (!view_of(blob, nbytes, sc, h)) return RT_ERR_INVALID;
     sc.compat = p->compat;
+    if (cam->time0 < h.valid0 || cam->time1 > h.valid1) return RT_ERR_UNSUPPORTED;
     if (cam->time0 >= h.shutter0 && cam->time1 <= h.shutter1 && cam->time0 <= cam->time1) sc.world_flat = h.world_flat; // as rt_render_accumulate
     RtCameraDev cd;
     int rc = rt_camera_derive(cam, &cd);
@@ -199,6 +202,7 @@ int hs_sample_radiance(const void* blob, size_t nbytes, const rt_camera* cam, co
     RtBlobHeader h;
     if (!view_of(blob, nbytes, sc, h)) return RT_ERR_INVALID;
     sc.compat = p->compat;
+    if (cam->time0 < h.valid0 || cam->time1 > h.valid1) return RT_ERR_UNSUPPORTED;
     if (cam->time0 >= h.shutter0 && cam->time1 <= h.shutter1 && cam->time0 <= cam->time1) sc.world_flat = h.world_flat; // as rt_render_accumulate
     RtCameraDev cd;
     int rc = rt_camera_derive(cam, &cd);
@@ -214,6 +218,7 @@ int hs_visit_stats(const void* blob, size_t nbytes, const rt_camera* cam, const 
     RtBlobHeader h;
     if (!view_of(blob, nbytes, sc, h)) return RT_ERR_INVALID;
     sc.compat = p->compat;
+    if (cam->time0 < h.valid0 || cam->time1 > h.valid1) return RT_ERR_UNSUPPORTED;
     if (cam->time0 >= h.shutter0 && cam->time1 <= h.shutter1 && cam->time0 <= cam->time1) sc.world_flat = h.world_flat; // as rt_render_accumulate
     RtCameraDev cd;
     int rc = rt_camera_derive(cam, &cd);

@@ -141,3 +141,50 @@ def test_moving_sphere_outside_the_interval_its_tree_bound_covers():
     a, _ = ck.hostsim_render(blob, cam, p, 2)
     b, _ = osc.render(cam, p, 2, threads=4)
     assert float((util.rel_err(a, b) > 1e-9).mean()) <= 0.002
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scene_graphs(seed):
+    """Random nestings of every hittable kind: lists inside BvhNodes inside instances, media over rotated boxes, moving
+    spheres under Translate, several levels deep. Builder flags: 0 = the compiler's own trees, 2 = the reference's
+    topology, 4 = valid for rays of any time (then some rays carry a time outside every [time0, time1])."""
+    for flags in (0, 2, 4):
+        try:
+            b, world = util.random_scene_graph(seed, flags)
+            blob, desc = b.compile(world), b.describe(world)
+        except api.RtError as e:          # deeper than the supported instance nesting: a documented limit
+            assert e.code == -2
+            continue
+        osc = ck.OracleScene(desc, share_bvh_axes=True)
+        rng = np.random.default_rng(1000 + seed)
+        rays = util.random_rays(rng, 1500, any_time=flags == 4)
+        xi = rng.random((len(rays), osc.n_media)) if osc.n_media else None
+        want = osc.trace_first_hit(rays, xi)
+        got, _ = ck.hostsim_trace_first_hit(blob, rays, xi)
+        rep = util.first_hit_report(got, want)
+        assert rep["prim_match"] == 1.0 and rep["t_bit_equal"] == 1.0, (seed, flags, rep)
+        assert (want["prim_id"] != MISS).mean() > 0.01
+
+
+def test_ray_times_outside_the_interval_a_bvh_over_moving_spheres_was_built_for():
+    """random_scene keeps ~390 moving spheres in BvhNode::new_(.., 0.0, 1.0): rebuilt by the compiler, that tree is right
+    for ray times in [0, 1] only and says so; compiled with flag 4 it is replayed in the reference's form for any time."""
+    import copy
+    _, info, blob, desc = util.build_scene("random_scene")
+    cam = copy.copy(info.camera)
+    cam.time0, cam.time1 = -1.0, 3.0
+    p = api.params_from_info(info, width=24, height=16, seed=util.RENDER_SEED)
+    with pytest.raises(RuntimeError):
+        ck.hostsim_render(blob, cam, p, 1)
+    rays = ck.oracle_generate_rays(cam, p, 0)
+    assert rays["time"].min() < 0.0 and rays["time"].max() > 1.0
+    with pytest.raises(RuntimeError):
+        ck.hostsim_trace_first_hit(blob, rays, None)
+    _, info, blob, desc = util.build_scene("random_scene", flags=4)
+    osc = ck.OracleScene(desc, share_bvh_axes=True)
+    got, _ = ck.hostsim_trace_first_hit(blob, rays, None)
+    rep = util.first_hit_report(got, osc.trace_first_hit(rays, None))
+    assert rep["prim_match"] == 1.0 and rep["t_bit_equal"] == 1.0, rep
+    a, _ = ck.hostsim_render(blob, cam, p, 2)
+    b, _ = osc.render(cam, p, 2, threads=4)
+    assert float((util.rel_err(a, b) > 1e-9).mean()) <= 0.002

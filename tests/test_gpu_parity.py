@@ -112,6 +112,46 @@ def test_camera_shutter_outside_the_moving_sphere_interval(gpu_ctx):
     scene.close()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scene_graphs_on_the_gpu(gpu_ctx, seed):
+    """Random nestings of every hittable kind (see the CPU test of the same name), traced by the kernels."""
+    for flags in (0, 4):
+        try:
+            b, world = util.random_scene_graph(seed, flags)
+            blob, desc = b.compile(world), b.describe(world)
+        except api.RtError as e:
+            assert e.code == -2
+            continue
+        osc = ck.OracleScene(desc, share_bvh_axes=True)
+        scene = gpu_ctx.upload(blob)
+        rng = np.random.default_rng(1000 + seed)
+        rays = util.random_rays(rng, 4000, any_time=flags == 4)
+        xi = rng.random((len(rays), osc.n_media)) if osc.n_media else None
+        rep = util.first_hit_report(gpu_ctx.trace_first_hit(scene, rays, xi), osc.trace_first_hit(rays, xi))
+        # (media are frequent in these scenes: log() differs in the last bit between the two libms for a few per cent of them)
+        assert rep["prim_match"] >= 0.9995 and rep["t_rel_max"] <= 1e-5 and rep["t_bit_equal"] >= 0.95, (seed, flags, rep)
+        scene.close()
+
+
+def test_shutter_outside_the_interval_of_a_bvh_over_moving_spheres(gpu_ctx):
+    import copy
+    _, info, blob, desc = util.build_scene("random_scene")
+    scene = gpu_ctx.upload(blob)
+    cam = copy.copy(info.camera)
+    cam.time0, cam.time1 = -1.0, 3.0
+    p = api.params_from_info(info, width=32, height=24, seed=util.RENDER_SEED)
+    with pytest.raises(api.RtError) as e:
+        gpu_ctx.render(scene, cam, p, 1)
+    assert e.value.code == -2
+    scene.close()
+    _, info, blob, desc = util.build_scene("random_scene", flags=4)
+    scene = gpu_ctx.upload(blob)
+    got = gpu_ctx.render(scene, cam, p, 2)
+    want, _ = ck.OracleScene(desc, share_bvh_axes=True).render(cam, p, 2)
+    assert float((util.rel_err(got, want) > 1e-9).mean()) <= 0.002
+    scene.close()
+
+
 def test_first_hit_edge_cases(gpu_ctx):
     _, info, blob, desc = util.build_scene("cornell_smoke")
     scene = gpu_ctx.upload(blob)

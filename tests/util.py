@@ -117,3 +117,76 @@ def oracle_visits(osc, info):
     return dict(VISITS_SHAPE, camera_samples=int(st.camera_samples), ray_segments=int(st.ray_segments), node_tests=int(st.node_tests),
                 sphere_tests=int(st.sphere_tests), moving_sphere_tests=int(st.moving_sphere_tests), rect_tests=int(st.rect_tests),
                 medium_tests=int(st.medium_tests))
+
+
+def random_scene_graph(seed, flags=0):
+    """A random scene graph over every hittable kind: primitives, Translate / RotateY chains, media, lists, BvhNodes,
+    nested in each other up to a few levels. -> (builder, world handle). Deterministic in `seed`."""
+    rng = np.random.default_rng(seed)
+    b = api.Builder(seed=SCENE_SEED + seed, flags=flags)
+    mats = [b.lambertian_color(0.6, 0.5, 0.4), b.metal(0.8, 0.8, 0.7, 0.2), b.dielectric(1.5), b.lambertian(b.noise(2.0)),
+            b.diffuse_light(b.solid(3.0, 3.0, 3.0))]
+
+    def mat():
+        return mats[int(rng.integers(len(mats)))]
+
+    def prim():
+        k = int(rng.integers(6))
+        c = rng.uniform(-8, 8, 3)
+        if k == 0:
+            return b.sphere(tuple(c), float(rng.uniform(0.3, 3.0)), mat())
+        if k == 1:
+            return b.moving_sphere(tuple(c), tuple(c + rng.uniform(-2, 2, 3)), 0.0, 1.0, float(rng.uniform(0.3, 2.0)), mat())
+        if k == 5:
+            return b.box(tuple(c), tuple(c + rng.uniform(0.5, 4.0, 3)), mat())
+        a0, b0 = rng.uniform(-8, 6, 2)
+        a1, b1 = a0 + rng.uniform(0.5, 6), b0 + rng.uniform(0.5, 6)
+        rect = (b.xy_rect, b.xz_rect, b.yz_rect)[k - 2]
+        return rect(float(a0), float(a1), float(b0), float(b1), float(rng.uniform(-8, 8)), mat())
+
+    def wrapped(h, most=3):
+        for _ in range(int(rng.integers(0, most + 1))):
+            if rng.random() < 0.5:
+                h = b.translate(h, tuple(rng.uniform(-4, 4, 3)))
+            else:
+                h = b.rotate_y(h, float(rng.uniform(-80, 80)))
+        return h
+
+    def medium():
+        boundary = (b.sphere(tuple(rng.uniform(-6, 6, 3)), float(rng.uniform(1.0, 4.0)), mats[0]) if rng.random() < 0.5 else
+                    b.box(tuple(rng.uniform(-8, 0, 3)), tuple(rng.uniform(1, 8, 3)), mats[0]))
+        return b.constant_medium(wrapped(boundary, 2), float(rng.uniform(0.05, 0.6)), 0.8, 0.8, 0.9)
+
+    def leafish():
+        r = rng.random()
+        if r < 0.15:
+            return medium()
+        return wrapped(prim(), 2) if r < 0.6 else prim()
+
+    def group(level):
+        members = []
+        for _ in range(int(rng.integers(2, 7))):
+            members.append(group(level - 1) if level > 0 and rng.random() < 0.3 else leafish())
+        lst = b.list(members)
+        r = rng.random()
+        if r < 0.6:
+            return wrapped(b.bvh(lst, 0.0, 1.0), 1)
+        return lst if r < 0.8 else wrapped(lst, 1)
+
+    top = []
+    for _ in range(int(rng.integers(2, 8))):
+        top.append(group(2) if rng.random() < 0.5 else leafish())
+    if rng.random() < 0.5:     # something that contains everything
+        top.append(b.constant_medium(b.sphere((0, 0, 0), 60.0, mats[0]), 0.01, 1.0, 1.0, 1.0))
+    return b, b.list(top)
+
+
+def random_rays(rng, n, any_time=True):
+    o = rng.uniform(-14, 14, (n, 3))
+    d = rng.normal(size=(n, 3))
+    inward = rng.random(n) < 0.5
+    d[inward] = rng.uniform(-6, 6, (int(inward.sum()), 3)) - o[inward]          # half of them aimed at the middle
+    t = rng.random(n)
+    if any_time:
+        t[rng.random(n) < 0.1] = 2.5                                              # some outside every [time0, time1]
+    return rays_from(o, d, time=t)
