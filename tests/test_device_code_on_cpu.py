@@ -188,3 +188,18 @@ def test_ray_times_outside_the_interval_a_bvh_over_moving_spheres_was_built_for(
     a, _ = ck.hostsim_render(blob, cam, p, 2)
     b, _ = osc.render(cam, p, 2, threads=4)
     assert float((util.rel_err(a, b) > 1e-9).mean()) <= 0.002
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scene_graphs_render_like_the_oracle(seed):
+    try:
+        b, world = util.random_scene_graph(seed, 0)
+        blob, desc = b.compile(world), b.describe(world)
+    except api.RtError as e:
+        assert e.code == -2
+        return
+    cam = api.make_camera((0, 2, -26), (0, 0, 0), (0, 1, 0), 40.0, 4 / 3, 0.1, 20.0, 0.0, 1.0)
+    p = api.make_params(20, 15, max_depth=12, background=(0.7, 0.8, 1.0), seed=77 + seed)
+    a, _ = ck.hostsim_render(blob, cam, p, 2)
+    w, _ = ck.OracleScene(desc, share_bvh_axes=True).render(cam, p, 2, threads=4)
+    assert float((util.rel_err(a, w) > 1e-9).mean()) == 0.0 and a.mean() > 0.0

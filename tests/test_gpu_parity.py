@@ -133,6 +133,23 @@ def test_random_scene_graphs_on_the_gpu(gpu_ctx, seed):
         scene.close()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_scene_graphs_render_on_the_gpu(gpu_ctx, seed):
+    try:
+        b, world = util.random_scene_graph(seed, 0)
+        blob, desc = b.compile(world), b.describe(world)
+    except api.RtError as e:
+        assert e.code == -2
+        return
+    cam = api.make_camera((0, 2, -26), (0, 0, 0), (0, 1, 0), 40.0, 4 / 3, 0.1, 20.0, 0.0, 1.0)
+    p = api.make_params(40, 30, max_depth=12, background=(0.7, 0.8, 1.0), seed=77 + seed, spp_per_pass=3)
+    scene = gpu_ctx.upload(blob)
+    got = gpu_ctx.render(scene, cam, p, 4)
+    want, _ = ck.OracleScene(desc, share_bvh_axes=True).render(cam, p, 4)
+    assert float((util.rel_err(got, want) > 1e-9).mean()) <= 0.005 and abs(got.mean() / want.mean() - 1.0) <= 1e-3
+    scene.close()
+
+
 def test_shutter_outside_the_interval_of_a_bvh_over_moving_spheres(gpu_ctx):
     import copy
     _, info, blob, desc = util.build_scene("random_scene")
