@@ -546,6 +546,7 @@ uint32_t rt_builder::emit_bvh(Flat& f, const ObjRec& o, int parent, uint32_t dep
     if (r == RT_REF_NONE) return RT_REF_NONE;
     set_box(f.nodes[gate].lo0, f.nodes[gate].hi0, o.tree[0].box);
     f.nodes[gate].c0 = r;
+    f.nodes[gate].pad[0] = RT_NODE_EXACT;
     return RT_MAKE_REF(RT_REF_NODE, gate);
 }
 
@@ -579,7 +580,7 @@ uint32_t rt_builder::emit_replay(Flat& f, const ObjRec& o, int node, int parent,
     const BNode& bn = o.tree[(size_t)node];
     const uint32_t me = (uint32_t)f.nodes.size();
     f.nodes.push_back(blank_node());
-    f.nodes[me].pad[0] = RT_NODE_ORDERED;
+    f.nodes[me].pad[0] = RT_NODE_ORDERED | RT_NODE_EXACT;
     uint32_t n0 = 0, n1 = 0, c0, c1 = RT_REF_NONE;
     if (bn.left_node >= 0) c0 = emit_replay(f, o, bn.left_node, parent, depth, n0);
     else c0 = emit(f, bn.left_obj, parent, depth, n0);
@@ -594,6 +595,7 @@ uint32_t rt_builder::emit_replay(Flat& f, const ObjRec& o, int node, int parent,
         if (r == RT_REF_NONE) return RT_REF_NONE;
         set_box(f.nodes[gate].lo0, f.nodes[gate].hi0, o.tree[(size_t)bn.right_node].box);
         f.nodes[gate].c0 = r;
+        f.nodes[gate].pad[0] = RT_NODE_EXACT;
         c1 = RT_MAKE_REF(RT_REF_NODE, gate);
     } else if (bn.right_obj != bn.left_obj || objs[bn.right_obj].kind == OBJ_MEDIUM) {
         // span-1 nodes (bvh.rs:33-35) hold the same object twice; the second test can never win for a
@@ -813,7 +815,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
             if (sequence[k].all) set_box_all(t.lo0, t.hi0); else set_box(t.lo0, t.hi0, sequence[k].box);
             t.c0 = sequence[k].ref;
             if (tree_ref != RT_REF_NONE) { set_box_all(t.lo1, t.hi1); t.c1 = tree_ref; }
-            t.pad[0] = RT_NODE_ORDERED;
+            t.pad[0] = RT_NODE_ORDERED | RT_NODE_EXACT;
             f.nodes.push_back(t);
             tree_ref = RT_MAKE_REF(RT_REF_NODE, f.nodes.size() - 1);
             need += 1u;
@@ -966,6 +968,13 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     hd.max_chain = f.max_chain;
     hd.flags = flags;
     hd.n_objects = (uint32_t)objs.size();
+    for (const RtNode& n : f.nodes) {
+        if (n.pad[0] & RT_NODE_EXACT) hd.n_exact_nodes += 1u;
+        const float* boxes[4] = {n.lo0, n.hi0, n.lo1, n.hi1};
+        for (const float* b : boxes)
+            for (int a = 0; a < 3; ++a)
+                if (std::isfinite(b[a])) hd.node_extent = std::max(hd.node_extent, (double)std::fabs(b[a]));
+    }
     memcpy(blob.data(), &hd, sizeof hd);
     void* out = malloc(blob.size());
     if (!out) return fail(RT_ERR_OOM, "out of memory");

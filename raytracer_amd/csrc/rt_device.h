@@ -35,6 +35,7 @@ struct DScene {
     uint32_t world, world_flat, world_tree;
     uint32_t n_media;
     uint32_t compat; // bit 0: book-correct RotateY back-rotation; bit 1: book-correct XY lens disk
+    double node_extent; // largest finite |coordinate| of any node box
 };
 #define RT_COMPAT_BOOK_ROTATE 1u
 #define RT_COMPAT_BOOK_LENS 2u
@@ -88,11 +89,25 @@ RT_HD Ray rt_ray_to_level(const DScene& sc, const Ray& wray, int32_t inst) {
 struct RtSlab {
     V3 inv; // 1 / d (aabb.rs:36,49,62)
     bool nx, ny, nz; // inv < 0 per axis (aabb.rs:39,52,65)
+    // Constants of the conservative f32 test (rt_node_boxes_f32): slab distance = bound * i - c, with c pushed
+    // outwards by the error bound (cn* for the near side, cf* for the far side).
+    float ix, iy, iz, cnx, cny, cnz, cfx, cfy, cfz;
 };
-RT_HD RtSlab rt_slab_of(const Ray& r) {
+// `extent`: largest |coordinate| of any box the ray will be tested against.
+RT_HD RtSlab rt_slab_of(const Ray& r, double extent) {
     RtSlab s;
     s.inv = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
     s.nx = s.inv.x < 0.0; s.ny = s.inv.y < 0.0; s.nz = s.inv.z < 0.0;
+    // f32 evaluation of (b - o) / d as fma(b, i, -c) with i = f32(1/d), c = f32(o/d): the result is off by at most
+    // 2^-24 (|b i| + |c|) for the rounding of i, as much again for the rounding of c and of the result - under
+    // 2^-22 (extent |1/d| + |o/d|). The margin is four times that.
+    const double mx = 0x1p-20 * (extent * fabs(s.inv.x) + fabs(r.o.x * s.inv.x));
+    const double my = 0x1p-20 * (extent * fabs(s.inv.y) + fabs(r.o.y * s.inv.y));
+    const double mz = 0x1p-20 * (extent * fabs(s.inv.z) + fabs(r.o.z * s.inv.z));
+    s.ix = (float)s.inv.x; s.iy = (float)s.inv.y; s.iz = (float)s.inv.z;
+    s.cnx = (float)(r.o.x * s.inv.x + mx); s.cfx = (float)(r.o.x * s.inv.x - mx);
+    s.cny = (float)(r.o.y * s.inv.y + my); s.cfy = (float)(r.o.y * s.inv.y - my);
+    s.cnz = (float)(r.o.z * s.inv.z + mz); s.cfz = (float)(r.o.z * s.inv.z - mz);
     return s;
 }
 RT_HD bool rt_aabb_hit(const float (&lo)[3], const float (&hi)[3], const Ray& r, const RtSlab& k, double t_min, double t_max,
@@ -108,6 +123,28 @@ RT_HD bool rt_aabb_hit(const float (&lo)[3], const float (&hi)[3], const Ray& r,
     t_max = t_far < t_max ? t_far : t_max;
     t_enter = t_near;
     return !(t_max <= t_near);
+}
+// Both boxes of a node whose boxes only cull (every box bounds what is below it, so entering a box the exact test
+// would have rejected changes nothing but the work): f32 throughout, every rounding taken outwards. A NaN slab
+// distance (0 * inf, inf - inf: a ray parallel to the slab) is ignored by fmaxf / fminf, which errs towards entering.
+// t_min rounded down, t_max rounded up; e0, e1: entry distances, good enough to choose the nearer child.
+RT_HD void rt_node_boxes_f32(const RtNode& n, const RtSlab& k, float t_min, float t_max, bool& h0, bool& h1, float& e0, float& e1) {
+    const float n0x = k.nx ? n.hi0[0] : n.lo0[0], f0x = k.nx ? n.lo0[0] : n.hi0[0];
+    const float n0y = k.ny ? n.hi0[1] : n.lo0[1], f0y = k.ny ? n.lo0[1] : n.hi0[1];
+    const float n0z = k.nz ? n.hi0[2] : n.lo0[2], f0z = k.nz ? n.lo0[2] : n.hi0[2];
+    const float n1x = k.nx ? n.hi1[0] : n.lo1[0], f1x = k.nx ? n.lo1[0] : n.hi1[0];
+    const float n1y = k.ny ? n.hi1[1] : n.lo1[1], f1y = k.ny ? n.lo1[1] : n.hi1[1];
+    const float n1z = k.nz ? n.hi1[2] : n.lo1[2], f1z = k.nz ? n.lo1[2] : n.hi1[2];
+    const float a0x = __builtin_fmaf(n0x, k.ix, -k.cnx), a0y = __builtin_fmaf(n0y, k.iy, -k.cny), a0z = __builtin_fmaf(n0z, k.iz, -k.cnz);
+    const float b0x = __builtin_fmaf(f0x, k.ix, -k.cfx), b0y = __builtin_fmaf(f0y, k.iy, -k.cfy), b0z = __builtin_fmaf(f0z, k.iz, -k.cfz);
+    const float a1x = __builtin_fmaf(n1x, k.ix, -k.cnx), a1y = __builtin_fmaf(n1y, k.iy, -k.cny), a1z = __builtin_fmaf(n1z, k.iz, -k.cnz);
+    const float b1x = __builtin_fmaf(f1x, k.ix, -k.cfx), b1y = __builtin_fmaf(f1y, k.iy, -k.cfy), b1z = __builtin_fmaf(f1z, k.iz, -k.cfz);
+    e0 = __builtin_fmaxf(__builtin_fmaxf(a0x, a0y), __builtin_fmaxf(a0z, t_min));
+    e1 = __builtin_fmaxf(__builtin_fmaxf(a1x, a1y), __builtin_fmaxf(a1z, t_min));
+    const float x0 = __builtin_fminf(__builtin_fminf(b0x, b0y), __builtin_fminf(b0z, t_max));
+    const float x1 = __builtin_fminf(__builtin_fminf(b1x, b1y), __builtin_fminf(b1z, t_max));
+    h0 = !(x0 < e0);
+    h1 = !(x1 < e1);
 }
 // One node record as four 16-byte loads (records are 64-byte aligned).
 RT_HD RtNode rt_load_node(const RtNode* p) {
@@ -366,15 +403,25 @@ struct GlobalNodes {
     const RtNode* nodes;
     RT_HD RtNode load(uint32_t index) const { return rt_load_node(nodes + index); }
 };
-template <class Stack, class Nodes>
+// EXACT_NODES = false: for scenes without a node flagged RT_NODE_EXACT (the flag is then not looked at).
+template <bool EXACT_NODES = true, class Stack, class Nodes>
 RT_HD void rt_trav_node_step(const Nodes& nodes, RtTrav& s, Stack& st, double t_min) {
     const RtNode n = nodes.load(RT_REF_INDEX(s.cur));
     RT_VISIT(0u);
-    double e0, e1;
-    const bool h0 = rt_aabb_hit(n.lo0, n.hi0, s.r, s.slab, t_min, s.best.t, e0);
-    const bool h1 = rt_aabb_hit(n.lo1, n.hi1, s.r, s.slab, t_min, s.best.t, e1);
+    bool h0, h1, swap;
+    if (EXACT_NODES && n.pad[0] != 0u) {
+        double e0, e1;
+        h0 = rt_aabb_hit(n.lo0, n.hi0, s.r, s.slab, t_min, s.best.t, e0);
+        h1 = rt_aabb_hit(n.lo1, n.hi1, s.r, s.slab, t_min, s.best.t, e1);
+        swap = e1 < e0 && (n.pad[0] & RT_NODE_ORDERED) == 0u;
+    } else {
+        const float lo = (float)t_min, hi = (float)s.best.t; // widened by an ulp each: the conversions round to nearest
+        float e0, e1;
+        rt_node_boxes_f32(n, s.slab, lo - __builtin_fabsf(lo) * 0x1p-23f, hi + __builtin_fabsf(hi) * 0x1p-23f, h0, h1, e0, e1);
+        swap = e1 < e0;
+    }
+    h1 = h1 && n.c1 != RT_REF_NONE; // (an absent child has the empty box, which a ray without direction would still "hit")
     if (h0 && h1) {
-        const bool swap = e1 < e0 && n.pad[0] == 0u;
         st.push(swap ? n.c0 : n.c1);
         s.cur = swap ? n.c1 : n.c0;
     } else if (h0 || h1) {
@@ -407,14 +454,14 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
         const RtInst in = sc.insts[idx];
         st.push(RT_MAKE_REF(RT_REF_POP, idx));
         s.r = rt_apply_inst(in, s.r);
-        s.slab = rt_slab_of(s.r);
+        s.slab = rt_slab_of(s.r, sc.node_extent);
         s.cur = in.child;
         return;
     }
     case RT_REF_POP: { // leave instance idx: back to the ray of its own frame
         const RtInst in = sc.insts[idx];
         s.r = rt_ray_to_level(sc, world_ray(), in.parent_inst);
-        s.slab = rt_slab_of(s.r);
+        s.slab = rt_slab_of(s.r, sc.node_extent);
         break;
     }
     default: rt_test_leaf(sc, s.cur, s.r, t_min, s.best, xi, skip_media); break;
@@ -428,7 +475,7 @@ RT_HD void rt_traverse(const DScene& sc, uint32_t root, const Ray& r, double t_m
                        bool skip_media, const RayFn& world_ray) {
     RtTrav s;
     s.r = r;
-    s.slab = rt_slab_of(r);
+    s.slab = rt_slab_of(r, sc.node_extent);
     s.best = best;
     s.cur = root;
     GlobalNodes nodes;

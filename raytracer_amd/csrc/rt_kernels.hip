@@ -271,6 +271,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtCameraDev cam, PassInfo p
 //  * box tests run for all lanes that hold a node until `leaf_min` lanes wait at a leaf; then those
 //    leaves are tested together.
 // Which lane traces which ray, and when, has no effect on results.
+template <bool EXACT_NODES> // false: the scene has no node whose box tests must reproduce the reference's f64 arithmetic
 __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
                                                                uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_min,
                                                                uint32_t n_cached) {
@@ -336,7 +337,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
                     PhiloxXi xi;
                     xi.pi = &pi; xi.id = id; xi.bounce = it;
                     rt_extend_flat(sc, held, 0.001, s.best, xi, false);
-                    s.slab = rt_slab_of(s.r);
+                    s.slab = rt_slab_of(s.r, sc.node_extent);
                     s.cur = sc.world_tree;
                     st.sp = 0u;
                     active = true;
@@ -351,7 +352,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             const bool at_node = active && RT_REF_TYPE(s.cur) == RT_REF_NODE;
             if (__ballot(at_node) == 0ull) break;
             if ((uint32_t)__popcll(__ballot(active && !at_node)) >= leaf_min) break;
-            if (at_node) rt_trav_node_step(nodes, s, st, 0.001);
+            if (at_node) rt_trav_node_step<EXACT_NODES>(nodes, s, st, 0.001);
         }
         // ---- one non-node reference for every lane that holds one ----
         if (active && s.cur != RT_REF_NONE && RT_REF_TYPE(s.cur) != RT_REF_NODE) {
@@ -676,6 +677,7 @@ void make_view(rt_scene* s) {
     v.world_tree = h.world_tree;
     v.n_media = h.n_media;
     v.compat = 0;
+    v.node_extent = h.node_extent;
 }
 
 int ensure_paths(rt_context* ctx, size_t paths, uint32_t max_depth) {
@@ -980,8 +982,10 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
     if (lds_stack_bytes + 16 > ctx->lds_per_block) return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "render: traversal stacks exceed the LDS of a workgroup");
     const uint32_t n_cached = (uint32_t)std::min<size_t>(sc->hdr.nodes.count, (ctx->lds_per_block - lds_stack_bytes - 16) / sizeof(RtNode));
     const size_t lds = lds_stack_bytes + (size_t)n_cached * sizeof(RtNode) + 16;
+    const bool exact_nodes = sc->hdr.n_exact_nodes != 0u;
+    const void* k_extend = exact_nodes ? (const void*)k_extend_tree<true> : (const void*)k_extend_tree<false>;
     if (lds > 65536)
-        RT_HIP(hipFuncSetAttribute((const void*)k_extend_tree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size of k_extend_tree");
+        RT_HIP(hipFuncSetAttribute(k_extend, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size of k_extend_tree");
     const uint32_t extend_blocks_per_cu = 1u;
     if (getenv("RT_DEBUG"))
         fprintf(stderr, "rt: lds_per_block %zu, stack_need %u, nodes %llu, cached %u, lds %zu\n", ctx->lds_per_block, stack_cap,
@@ -1012,8 +1016,12 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
         const uint32_t g_sh = grid_for(ctx, paths, 8);
         for (uint32_t it = 0; it < p->max_depth; ++it) {
             a = tm.begin();
-            hipLaunchKernelGGL(k_extend_tree, dim3(g_ext), dim3(RT_TREE_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it, stack_cap,
-                               ctx->tune_refill, ctx->tune_leaf, n_cached);
+            if (exact_nodes)
+                hipLaunchKernelGGL(k_extend_tree<true>, dim3(g_ext), dim3(RT_TREE_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it,
+                                   stack_cap, ctx->tune_refill, ctx->tune_leaf, n_cached);
+            else
+                hipLaunchKernelGGL(k_extend_tree<false>, dim3(g_ext), dim3(RT_TREE_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it,
+                                   stack_cap, ctx->tune_refill, ctx->tune_leaf, n_cached);
             tm.end(a, 1);
             a = tm.begin();
             hipLaunchKernelGGL(k_shade_main, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);

@@ -10,7 +10,7 @@
 #include <stdint.h>
 
 #define RT_BLOB_MAGIC 0x31425452u /* "RTB1" little endian */
-#define RT_BLOB_VERSION 9u
+#define RT_BLOB_VERSION 10u
 
 // ---- tagged references -------------------------------------------------------------------------
 enum RtRefType : uint32_t {
@@ -52,6 +52,7 @@ struct RtNode {
     uint32_t pad[2];      // pad[0]: RT_NODE_* flags
 };
 #define RT_NODE_ORDERED 1u /* child 0 is entered (and finished) before child 1 whatever their distances */
+#define RT_NODE_EXACT 2u   /* what the reference finds depends on the verdict of these box tests: they are evaluated in the reference's f64 arithmetic (aabb.rs:35-75); boxes of other nodes only cull and are tested conservatively in f32 */
 
 // Common per-primitive bookkeeping, one per geometry record (same index).
 struct RtMeta {
@@ -128,6 +129,8 @@ struct RtBlobHeader {
     uint32_t n_objects;      // host handles issued (prim_id range)
     double shutter0, shutter1; // ray times for which world_flat suffices: the moving spheres listed only in world_flat_any_time keep to their tree bounds (-inf, +inf when there are none)
     double valid0, valid1;     // ray times the blob may be traced with at all: those the BvhNodes holding moving spheres were built for (bvh.rs:15, time0..time1); (-inf, +inf) without such nodes or with RT_BLOB_FLAG_ANY_TIME
+    double node_extent;        // largest finite |coordinate| of any node box (0 without nodes): scales the error bound of the f32 box test
+    uint64_t n_exact_nodes;    // nodes flagged RT_NODE_EXACT
     RtSection nodes, spheres, sphere_meta, mspheres, msphere_meta, rects, rect_meta, boxes, box_meta,
         media, insts, list_entries, materials, textures, perlin_vec, perlin_perm, texels;
 };

@@ -68,6 +68,7 @@ bool view_of(const void* blob, size_t nbytes, DScene& v, RtBlobHeader& h) {
     v.world_tree = h.world_tree;
     v.n_media = h.n_media;
     v.compat = 0;
+    v.node_extent = h.node_extent;
     return true;
 }
 

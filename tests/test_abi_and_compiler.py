@@ -81,11 +81,11 @@ def test_unsupported_shapes_are_refused_at_compile_time():
     assert e.value.code == _lib.RT_ERR_UNSUPPORTED
 
 
-HEADER = struct.Struct("<IIQIIIIIIIIdddd")  # magic, version, total, world_flat_any_time, world_flat, world_tree, n_media, stack_need, max_chain, flags, n_objects, shutter0, shutter1, valid0, valid1
+HEADER = struct.Struct("<IIQIIIIIIIIdddddQ")  # magic, version, total, world_flat_any_time, world_flat, world_tree, n_media, stack_need, max_chain, flags, n_objects, shutter0, shutter1, valid0, valid1
 
 
 def header(blob):
-    magic, version, total, world, world_flat, world_tree, n_media, stack_need, max_chain, flags, n_objects, shutter0, shutter1, valid0, valid1 = HEADER.unpack_from(blob, 0)
+    magic, version, total, world, world_flat, world_tree, n_media, stack_need, max_chain, flags, n_objects, shutter0, shutter1, valid0, valid1, node_extent, n_exact_nodes = HEADER.unpack_from(blob, 0)
     secs = np.frombuffer(blob, dtype="<u8", count=17 * 2, offset=HEADER.size).reshape(17, 2)
     names = ["nodes", "spheres", "sphere_meta", "mspheres", "msphere_meta", "rects", "rect_meta", "boxes", "box_meta", "media",
              "insts", "list_entries", "materials", "textures", "perlin_vec", "perlin_perm", "texels"]

@@ -31,7 +31,7 @@ def test_oracle_and_device_code_reproduce_golden(name):
     assert np.array_equal(hits["prim_id"], g["hits"]["prim_id"]) and same_bits(hits["t"], g["hits"]["t"])
     sim, _ = ck.hostsim_trace_first_hit(blob, g["rays"], xi)
     rep = util.first_hit_report(sim, g["hits"])
-    assert rep["prim_match"] == 1.0 and rep["ties"] < 0.01 and same_bits(sim["t"], g["hits"]["t"])
+    assert rep["prim_match"] == 1.0 and rep["ties"] < 0.02 and same_bits(sim["t"], g["hits"]["t"])
     p = api.params_from_info(info, width=20, height=15, seed=util.RENDER_SEED)
     img, st = osc.render(info.camera, p, 4, threads=2)
     assert same_bits(img, g["image"]) and st.ray_segments == int(g["segments"])
