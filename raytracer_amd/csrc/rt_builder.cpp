@@ -330,6 +330,11 @@ uint32_t rt_builder::emit(Flat& f, int h, int parent, uint32_t depth, uint32_t& 
         uint32_t c = emit(f, o.child, (int)me, depth + 1, cneed);
         if (c == RT_REF_NONE) return RT_REF_NONE;
         f.insts[me].child = c;
+        {   // only further instances and then one primitive or medium below: the traversal tests it without entering a frame
+            int b = o.child;
+            while (objs[b].kind == OBJ_TRANSLATE || objs[b].kind == OBJ_ROTATE_Y) b = objs[b].child;
+            if (objs[b].kind != OBJ_BVH && objs[b].kind != OBJ_LIST) f.insts[me].op |= RT_INST_LEAF;
+        }
         need = std::max(2u, 1u + cneed);
         return RT_MAKE_REF(RT_REF_INST, me);
     }
@@ -660,7 +665,11 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         default: return true;
         }
     };
-    struct Item { int handle; bool bounded; AABB box; bool flatable; bool timed; };
+    struct Item { int handle; bool bounded; AABB box; bool flatable; bool timed; int wrapped; };
+    // A member of a BvhNode or list that stands under instances, taken out to be an entry of its own under the same
+    // instances: `chain` = the Translate/RotateY objects from the outside in, `sub` = the member.
+    struct Wrapped { std::vector<int> chain; int sub; };
+    std::vector<Wrapped> wrapped;
     struct Run { uint32_t ref = RT_REF_NONE; AABB box = kEmptyBox; bool all = false; }; // all: every ray must enter it
     TimeSpan shutter = {-kInf, kInf}; // ray times for which the bounds of all moving spheres put under the tree hold
     std::vector<uint32_t> flat_refs, timed_refs;
@@ -685,10 +694,64 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         std::vector<Item> items;
         for (int m : members) {
             const ObjRec& o = objs[m];
+            {   // Translate/RotateY over a BvhNode with true boxes, or over a list, of plain static primitives: the same
+                // hits as every member under those instances by itself (hittable.rs:67-90, 145-178 move the ray and
+                // hand it down; a tree or list under them returns its members' nearest hit). As entries of their own
+                // the members go under the world's tree with bounds in the world's frame, and a lane never has to
+                // change frames to walk a tree.
+                Wrapped w;
+                int inner = m;
+                while (objs[inner].kind == OBJ_TRANSLATE || objs[inner].kind == OBJ_ROTATE_Y) { w.chain.push_back(inner); inner = objs[inner].child; }
+                const ObjRec& io = objs[inner];
+                const std::vector<int>* subs = nullptr;
+                if (io.kind == OBJ_BVH && io.exact_bounds && !(flags & RT_BLOB_FLAG_REFERENCE_TREE)) subs = &objs[io.child].members;
+                else if (io.kind == OBJ_LIST) subs = &io.members;
+                bool plain = subs && !w.chain.empty() && w.chain.size() <= RT_MAX_CHAIN && !subs->empty();
+                if (plain)
+                    for (int sub : *subs) {
+                        const ObjKind k = objs[sub].kind;
+                        plain = plain && (k == OBJ_SPHERE || k == OBJ_XYRECT || k == OBJ_XZRECT || k == OBJ_YZRECT || k == OBJ_BOX);
+                    }
+                if (plain) {
+                    for (int sub : *subs) {
+                        Item it;
+                        it.handle = sub; it.flatable = false; it.timed = false;
+                        it.bounded = bounding_box(sub, 0.0, 0.0, it.box);
+                        if (!it.bounded) { run_rc = fail(RT_ERR_PANIC, "No bounding box"); return out; }
+                        const bool ball = objs[sub].kind == OBJ_SPHERE;
+                        double c[3] = {objs[sub].d[0], objs[sub].d[1], objs[sub].d[2]};
+                        for (size_t k = w.chain.size(); k-- > 0;) { // from the member's frame out to the world's
+                            const ObjRec& in = objs[w.chain[k]];
+                            if (in.kind == OBJ_TRANSLATE) {
+                                for (int a = 0; a < 3; ++a) { it.box.lo[a] += in.d[a]; it.box.hi[a] += in.d[a]; c[a] += in.d[a]; }
+                            } else { // RotateY: d[0] = sin, d[1] = cos; a point of the child's frame lands at (cos x + sin z, y, cos z - sin x)
+                                const AABB b = it.box;
+                                it.box = kEmptyBox;
+                                for (int i = 0; i < 8; ++i) {
+                                    const double x = (i & 1) ? b.hi[0] : b.lo[0], y = (i & 2) ? b.hi[1] : b.lo[1], z = (i & 4) ? b.hi[2] : b.lo[2];
+                                    const double t[3] = {in.d[1] * x + in.d[0] * z, y, in.d[1] * z - in.d[0] * x};
+                                    for (int a = 0; a < 3; ++a) { it.box.lo[a] = std::min(it.box.lo[a], t[a]); it.box.hi[a] = std::max(it.box.hi[a], t[a]); }
+                                }
+                                const double cx = in.d[1] * c[0] + in.d[0] * c[2], cz = in.d[1] * c[2] - in.d[0] * c[0];
+                                c[0] = cx; c[2] = cz;
+                            }
+                        }
+                        if (ball) // a sphere stays a sphere: its centre carried out, the radius around it
+                            for (int a = 0; a < 3; ++a) { it.box.lo[a] = c[a] - std::fabs(objs[sub].d[3]); it.box.hi[a] = c[a] + std::fabs(objs[sub].d[3]); }
+                        if (!add_margin(it.box)) { run_rc = fail(RT_ERR_PANIC, "No bounding box"); return out; }
+                        it.wrapped = (int)wrapped.size();
+                        w.sub = sub;
+                        wrapped.push_back(w);
+                        items.push_back(it);
+                    }
+                    continue;
+                }
+            }
             if (o.kind == OBJ_BVH && o.exact_bounds && !(flags & RT_BLOB_FLAG_REFERENCE_TREE)) {
                 limit_time(o);
                 for (int sub : objs[o.child].members) {
                     Item it;
+                    it.wrapped = -1;
                     it.handle = sub; it.flatable = flatable(sub); it.timed = false;
                     it.bounded = bounding_box(sub, o.d[0], o.d[1], it.box);
                     if (!it.bounded) { run_rc = fail(RT_ERR_PANIC, "No bounding box"); return out; }
@@ -697,6 +760,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
                 continue;
             }
             Item it;
+            it.wrapped = -1;
             it.handle = m;
             it.flatable = flatable(m);
             // a moving sphere (possibly under instances, or as a medium's boundary) may go under the tree with the bound of
@@ -736,7 +800,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
                     handle_timed[(size_t)it.handle] = 1;
                 }
                 SahItem si;
-                si.obj = it.handle; si.box = it.box;
+                si.obj = it.wrapped >= 0 ? (int)objs.size() + it.wrapped : it.handle; si.box = it.box;
                 for (int a = 0; a < 3; ++a) si.c[a] = 0.5 * (it.box.lo[a] + it.box.hi[a]);
                 sah.push_back(si);
                 continue;
@@ -757,6 +821,27 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
             }
             uint32_t n = 0;
             out.ref = emit_ordered(f, tree, root, [&](int obj, uint32_t& ln) {
+                if ((size_t)obj >= objs.size()) { // a member under its instances: the instance records anew, then the member below them
+                    const Wrapped& w = wrapped[(size_t)obj - objs.size()];
+                    int parent = RT_NO_PARENT;
+                    uint32_t first = RT_REF_NONE;
+                    for (size_t k = 0; k < w.chain.size(); ++k) {
+                        const ObjRec& io = objs[w.chain[k]];
+                        RtInst in;
+                        in.a = io.d[0]; in.b = io.d[1]; in.c = io.d[2];
+                        in.op = (io.kind == OBJ_TRANSLATE ? RT_OP_TRANSLATE : RT_OP_ROTATE_Y) | RT_INST_LEAF;
+                        in.child = RT_REF_NONE; in.parent_inst = parent; in.src_id = (uint32_t)w.chain[k];
+                        const uint32_t me = (uint32_t)f.insts.size();
+                        f.insts.push_back(in);
+                        if (k == 0) first = RT_MAKE_REF(RT_REF_INST, me); else f.insts[(size_t)parent].child = RT_MAKE_REF(RT_REF_INST, me);
+                        parent = (int)me;
+                    }
+                    f.max_chain = std::max(f.max_chain, (uint32_t)w.chain.size());
+                    const uint32_t c = emit(f, w.sub, parent, (uint32_t)w.chain.size(), ln);
+                    if (c == RT_REF_NONE) return (uint32_t)RT_REF_NONE;
+                    f.insts[(size_t)parent].child = c;
+                    return first;
+                }
                 const uint32_t r = emit(f, obj, RT_NO_PARENT, 0, ln);
                 if (handle_timed[(size_t)obj] && r != RT_REF_NONE) timed_refs.push_back(r);
                 return r;

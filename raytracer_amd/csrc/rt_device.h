@@ -44,7 +44,7 @@ struct DScene {
 // Ray as the child of `inst` sees it. Translate: hittable.rs:71; RotateY: hittable.rs:149-158.
 RT_HD Ray rt_apply_inst(const RtInst& in, const Ray& r) {
     Ray o = r;
-    if (in.op == RT_OP_TRANSLATE) {
+    if ((in.op & RT_OP_MASK) == RT_OP_TRANSLATE) {
         o.o = r.o - v3(in.a, in.b, in.c);
     } else {
         const double s = in.a, c = in.b;
@@ -286,8 +286,10 @@ RT_HD bool rt_boundary_t(const DScene& sc, uint32_t ref, Ray r, double t_min, do
     }
 }
 
-// ConstantMedium::hit (constant_medium.rs:25-66). `xi` is the uniform the reference draws at :53.
-RT_HD bool rt_medium_t(const DScene& sc, const RtMedium& m, const Ray& r, double t_min, double t_max, double xi,
+// ConstantMedium::hit (constant_medium.rs:25-66). `xi(medium_index)` is the uniform the reference draws at :53; it is
+// only asked for once the ray is known to cross the boundary.
+template <class XiFn>
+RT_HD bool rt_medium_t(const DScene& sc, const RtMedium& m, const Ray& r, double t_min, double t_max, const XiFn& xi,
                        double& t_out) {
     double t1 = 0.0, t2 = 0.0;
     {   // boundary.hit(r, -inf, inf) then boundary.hit(r, rec1.t + 0.0001, inf) (constant_medium.rs:29-34); written as a
@@ -305,7 +307,7 @@ RT_HD bool rt_medium_t(const DScene& sc, const RtMedium& m, const Ray& r, double
     if (t1 < 0.0) t1 = 0.0;
     const double ray_length = v3_len(r.d);
     const double distance_inside_boundary = (t2 - t1) * ray_length;
-    const double hit_distance = m.neg_inv_density * log(xi);
+    const double hit_distance = m.neg_inv_density * log(xi(m.medium_index));
     if (hit_distance > distance_inside_boundary) return false;
     t_out = t1 + hit_distance / ray_length;
     return true;
@@ -369,7 +371,7 @@ RT_HD void rt_test_leaf(const DScene& sc, uint32_t ref, const Ray& r, double t_m
     case RT_REF_MEDIUM: {
         if (!skip_media) {
             const RtMedium m = sc.media[idx];
-            if (rt_medium_t(sc, m, r, t_min, best.t, xi(m.medium_index), t)) { best.t = t; best.ref = ref; best.aux = 0u; }
+            if (rt_medium_t(sc, m, r, t_min, best.t, xi, t)) { best.t = t; best.ref = ref; best.aux = 0u; }
         }
         break;
     }
@@ -440,31 +442,47 @@ template <class Stack, class XiFn, class RayFn>
 RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, const XiFn& xi, bool skip_media,
                          const RayFn& world_ray) {
     const uint32_t idx = RT_REF_INDEX(s.cur);
-    switch (RT_REF_TYPE(s.cur)) {
-    case RT_REF_LIST: { // HittableList: entries in order (hittable_list.rs:45-51)
+    const uint32_t type = RT_REF_TYPE(s.cur);
+    if (type == RT_REF_LIST) { // HittableList: entries in order (hittable_list.rs:45-51)
         const uint32_t e = sc.list_entries[idx];
         if (e != RT_REF_NONE) {
             st.push(RT_MAKE_REF(RT_REF_LIST, idx + 1u));
             s.cur = e;
             return;
         }
-        break;
-    }
-    case RT_REF_INST: {
-        const RtInst in = sc.insts[idx];
-        st.push(RT_MAKE_REF(RT_REF_POP, idx));
-        s.r = rt_apply_inst(in, s.r);
-        s.slab = rt_slab_of(s.r, sc.node_extent);
-        s.cur = in.child;
-        return;
-    }
-    case RT_REF_POP: { // leave instance idx: back to the ray of its own frame
-        const RtInst in = sc.insts[idx];
-        s.r = rt_ray_to_level(sc, world_ray(), in.parent_inst);
-        s.slab = rt_slab_of(s.r, sc.node_extent);
-        break;
-    }
-    default: rt_test_leaf(sc, s.cur, s.r, t_min, s.best, xi, skip_media); break;
+    } else if (type == RT_REF_POP) { // leave instance idx: back to the ray of its own frame
+        if (!st.empty()) { // (else nothing is left to test in the frame the lane would return to)
+            const RtInst in = sc.insts[idx];
+            s.r = rt_ray_to_level(sc, world_ray(), in.parent_inst);
+            s.slab = rt_slab_of(s.r, sc.node_extent);
+        }
+    } else {
+        uint32_t leaf = s.cur;
+        bool moved = false;
+        int32_t back_to = RT_NO_PARENT;
+        if (type == RT_REF_INST) {
+            RtInst in = sc.insts[idx];
+            if ((in.op & RT_INST_LEAF) == 0u) { // a subtree in its own frame: enter it, leave through a POP marker
+                st.push(RT_MAKE_REF(RT_REF_POP, idx));
+                s.r = rt_apply_inst(in, s.r);
+                s.slab = rt_slab_of(s.r, sc.node_extent);
+                s.cur = in.child;
+                return;
+            }
+            // one primitive seen through instances: move the ray, test, take the frame's ray back - the box-test
+            // constants stay those of the frame
+            back_to = in.parent_inst;
+            moved = true;
+#pragma unroll 1
+            for (int guard = 0;; ++guard) {
+                s.r = rt_apply_inst(in, s.r);
+                leaf = in.child;
+                if (RT_REF_TYPE(leaf) != RT_REF_INST || guard >= RT_MAX_CHAIN) break;
+                in = sc.insts[RT_REF_INDEX(leaf)];
+            }
+        }
+        rt_test_leaf(sc, leaf, s.r, t_min, s.best, xi, skip_media);
+        if (moved) s.r = rt_ray_to_level(sc, world_ray(), back_to);
     }
     s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop();
 }
@@ -616,7 +634,7 @@ RT_HD HitRec rt_reconstruct(const DScene& sc, const Ray& wray, const RtHitLite& 
     for (int k = 0; k < RT_MAX_CHAIN; ++k) {
         if (chain[k] >= 0) {
             const RtInst in = sc.insts[chain[k]];
-            if (in.op == RT_OP_TRANSLATE) {
+            if ((in.op & RT_OP_MASK) == RT_OP_TRANSLATE) {
                 rec.p = rec.p + v3(in.a, in.b, in.c);
                 rt_set_face_normal(rec, dchild[k], rec.normal);
             } else {

@@ -271,6 +271,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtCameraDev cam, PassInfo p
 //  * box tests run for all lanes that hold a node until `leaf_min` lanes wait at a leaf; then those
 //    leaves are tested together.
 // Which lane traces which ray, and when, has no effect on results.
+#ifdef RT_PHASE_STATS
+// Debug build only: how the waves of k_extend_tree spend their iterations, by bounce (0, 1, 2, 3+).
+__device__ unsigned long long g_phase[4][48];
+#define RT_PHASE_ADD(k, v) (ph[k] += (v))
+#else
+#define RT_PHASE_ADD(k, v) ((void)0)
+#endif
 template <bool EXACT_NODES> // false: the scene has no node whose box tests must reproduce the reference's f64 arithmetic
 __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
                                                                uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_min,
@@ -316,15 +323,20 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
         const unsigned long long piece = (unsigned long long)(v >> shift) * gridDim.x + blockIdx.x;
         return (piece << shift) + (v & ((1u << shift) - 1u));
     };
+#ifdef RT_PHASE_STATS
+    unsigned long long ph[48] = {};
+#endif
 #pragma unroll 1
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         if (n_idle == 64u && exhausted) break;
+        RT_PHASE_ADD(0, 1); RT_PHASE_ADD(7, 64u - n_idle);
         if (n_idle >= refill_min && !exhausted) { // hand idle lanes the next rays
             uint32_t v0 = 0u;
             if (lane == 0u) v0 = atomicAdd(&blk_taken, n_idle);
             v0 = __shfl(v0, 0);
+            RT_PHASE_ADD(1, 1); RT_PHASE_ADD(2, n_idle);
             if (!active) {
                 const unsigned long long i = index_of(v0 + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)));
                 if (i < n) {
@@ -352,9 +364,21 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             const bool at_node = active && RT_REF_TYPE(s.cur) == RT_REF_NODE;
             if (__ballot(at_node) == 0ull) break;
             if ((uint32_t)__popcll(__ballot(active && !at_node)) >= leaf_min) break;
+            RT_PHASE_ADD(3, 1); RT_PHASE_ADD(4, __popcll(__ballot(at_node)));
             if (at_node) rt_trav_node_step<EXACT_NODES>(nodes, s, st, 0.001);
         }
         // ---- one non-node reference for every lane that holds one ----
+#ifdef RT_PHASE_STATS
+        {
+            const bool v = active && s.cur != RT_REF_NONE && RT_REF_TYPE(s.cur) != RT_REF_NODE;
+            const unsigned long long any = __ballot(v);
+            if (any) { ph[5] += 1; ph[6] += __popcll(any); }
+            for (uint32_t ty = 0; ty < 16u; ++ty) {
+                const unsigned long long m = __ballot(v && RT_REF_TYPE(s.cur) == ty);
+                if (m) { ph[8 + ty] += 1; ph[24 + ty] += __popcll(m); }
+            }
+        }
+#endif
         if (active && s.cur != RT_REF_NONE && RT_REF_TYPE(s.cur) != RT_REF_NODE) {
             SlotRay ray_of;
             ray_of.rec = rays + path;
@@ -369,6 +393,10 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             active = false;
         }
     }
+#ifdef RT_PHASE_STATS
+    if (lane == 0u)
+        for (int k = 0; k < 48; ++k) if (ph[k]) atomicAdd(&g_phase[it < 3u ? it : 3u][k], ph[k]);
+#endif
 }
 
 // emitted + scatter (main.rs:60-70) for every path of iteration `it` that hit a material of type MAT.
@@ -1037,6 +1065,17 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
         RT_HIP(hipMemcpyAsync(host_counters.data(), ctx->counters, n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream),
                "read counters");
         RT_HIP(hipStreamSynchronize(ctx->stream), "render pass");
+#ifdef RT_PHASE_STATS
+        {
+            unsigned long long h[4][48];
+            RT_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h), "phase stats");
+            for (int g = 0; g < 4; ++g) {
+                fprintf(stderr, "phase[bounce %d%s]:", g, g == 3 ? "+" : "");
+                for (int k = 0; k < 48; ++k) fprintf(stderr, " %llu", h[g][k]);
+                fprintf(stderr, "\n");
+            }
+        }
+#endif
         if (stats) {
             stats->passes += 1;
             stats->camera_samples += paths;

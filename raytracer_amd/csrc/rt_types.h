@@ -77,6 +77,8 @@ struct RtMedium {
     uint32_t pad;
 };
 enum RtInstOp : uint32_t { RT_OP_TRANSLATE = 0, RT_OP_ROTATE_Y = 1 };
+#define RT_OP_MASK 0xFFu    /* RtInst::op: the operation ... */
+#define RT_INST_LEAF 0x100u /* ... and this flag: below the record are only further Translate/RotateY records and then one primitive or medium */
 struct RtInst {
     double a, b, c;      // translate: offset xyz; rotate_y: a = sin(theta), b = cos(theta)
     uint32_t op;

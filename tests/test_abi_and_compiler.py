@@ -118,14 +118,15 @@ def test_blob_layout_of_the_book2_final_scene():
     assert h["magic"] == 0x31425452 and h["total"] == len(blob) and len(blob) % 256 == 0
     s = h["sections"]
     # The world list holds 11 entries (main.rs:576-688). One is tested by every lane in lock step: the r=5000 medium that
-    # contains the whole scene. The BvhNode of 400 boxes is dissolved; its boxes and the other 9 entries (8 primitives /
-    # media + the instanced cluster) form one tree of 409 leaves = 408 nodes; the cluster's own tree over 1000 spheres
-    # has 999. The moving sphere sits in the tree under the bound of its own time interval [0, 1] and, for rays of
-    # other times, on the second lock-step list as well.
-    assert s["nodes"][1] == 408 + 999
+    # contains the whole scene. The BvhNode of 400 boxes is dissolved, and so is the instanced cluster - Translate over
+    # RotateY over a BvhNode of 1000 spheres becomes 1000 spheres each under its own copy of the two instance records,
+    # bounded in the world's frame: one tree of 400 + 8 + 1000 leaves = 1407 nodes, no frame change while walking it.
+    # The moving sphere sits in the tree under the bound of its own time interval [0, 1] and, for rays of other times,
+    # on the second lock-step list as well.
+    assert s["nodes"][1] == 1407
     assert s["boxes"][1] == 400 and s["mspheres"][1] == 1 and s["rects"][1] == 1
     assert s["spheres"][1] == 1000 + 5 + 2            # + the two medium boundaries (one is the shared r=70 sphere again)
-    assert s["media"][1] == 2 == h["n_media"] and s["insts"][1] == 2 and h["max_chain"] == 2
+    assert s["media"][1] == 2 == h["n_media"] and s["insts"][1] == 2000 and h["max_chain"] == 2
     assert s["texels"][1] == 1024 * 512 * 3 and s["perlin_vec"][1] == 768 and s["perlin_perm"][1] == 768
     assert all(off % 256 == 0 for off, _ in s.values())
     assert 2 <= h["stack_need"] <= 40
@@ -146,13 +147,22 @@ def test_blob_layout_of_the_book2_final_scene():
     # everything in the tree: ground boxes x, z in [-1000, 1000), the light at y = 554, the cluster up to z < 620
     assert np.all(lo <= [-1000, 0, -1000]) and np.all(lo > [-1001, -1, -1001])
     assert np.all(hi >= [1000 - 1, 554, 1000 - 1]) and np.all(hi < [1001, 600, 1001])
-    # the instanced cluster hangs under some node as a Translate instance with its world-space bound:
-    # spheres r=10 with centres in [0,165)^3, rotated 15 degrees about y, moved by (-100,270,395)
+    # the cluster's spheres hang under the tree as Translate records flagged as leaves (op = 0 | 0x100), each with the
+    # world-space bound of its sphere: r=10, centres in [0,165)^3 rotated 15 degrees about y and moved by (-100,270,395)
     found = [(n["lo0"], n["hi0"]) for n in nodes if n["c0"] >> 28 == 7] + [(n["lo1"], n["hi1"]) for n in nodes if n["c1"] >> 28 == 7]
-    assert len(found) == 1
-    wlo, whi = found[0]
-    assert np.all(wlo < [-100, 265, 345]) and np.all(whi > [60, 430, 540])
+    assert len(found) == 1000
+    wlo = np.min([f[0] for f in found], axis=0)
+    whi = np.max([f[1] for f in found], axis=0)
+    assert np.all(wlo < [-100, 265, 350]) and np.all(whi > [60, 430, 540])
     assert np.all(wlo > [-170, 250, 330]) and np.all(whi < [130, 450, 620])
+    assert all(np.all(np.abs((f[1] - f[0]) - 20.0) < 0.01) for f in found)
+    INST = np.dtype([("a", "<f8"), ("b", "<f8"), ("c", "<f8"), ("op", "<u4"), ("child", "<u4"), ("parent", "<i4"), ("src", "<u4")])
+    insts = np.frombuffer(blob, dtype=INST, count=s["insts"][1], offset=s["insts"][0])
+    assert set(insts["op"].tolist()) == {0x100, 0x101}
+    outer = insts[insts["parent"] < 0]
+    assert len(outer) == 1000 and np.all(outer["op"] == 0x100) and np.all(outer["child"] >> 28 == 7)
+    inner = insts[insts["parent"] >= 0]
+    assert np.all(inner["op"] == 0x101) and np.all(inner["child"] >> 28 == 2)
 
 
 def test_cornell_replays_the_reference_order():
