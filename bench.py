@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp", type=int, default=256, help="samples per pixel per GPU per step")
+    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step (halved until the path state fits the GPU)")
     ap.add_argument("--scene", default="final_scene")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     args = ap.parse_args()
@@ -122,11 +122,31 @@ def main():
         scene = ctx.upload(blob)
 
     W, H = info.width, info.height
-    spp_step = args.spp * world
-    params = api.params_from_info(info, seed=render_seed, tile=rdist.DEFAULT_TILE, tile_rank=rank, tile_world=world,
-                                  spp_per_pass=spp_step, profile=1)
-    d_sum = torch.zeros(W * H * 3, dtype=torch.float64, device=device)
-    torch.cuda.synchronize()  # the library launches on its own stream: the buffer must be zeroed before it is handed over
+    # One step = one pass of spp_step samples per pixel: the 50 bounces of a pass are 50 dependent rounds of launches, each
+    # with a latency floor, so a pass is made as large as the HBM takes (264 B of path state per path: 1024 spp of this
+    # GPU's share of 800x800 pixels = 173 GB). The first pass allocates; if it does not fit, every rank halves together.
+    while True:
+        spp_step = args.spp * world
+        params = api.params_from_info(info, seed=render_seed, tile=rdist.DEFAULT_TILE, tile_rank=rank, tile_world=world,
+                                      spp_per_pass=spp_step, profile=1)
+        d_sum = torch.zeros(W * H * 3, dtype=torch.float64, device=device)
+        torch.cuda.synchronize()  # the library launches on its own stream: the buffer must be zeroed before it is handed over
+        fits = torch.ones(1, dtype=torch.int32, device=device)
+        try:
+            ctx.render_accumulate(scene, info.camera, params, 0, spp_step, d_sum.data_ptr(), api.rt_stats())
+        except api.RtError as e:
+            if e.code != -4:  # RT_ERR_OOM
+                raise
+            fits.zero_()
+        if world > 1:
+            dist.all_reduce(fits, op=dist.ReduceOp.MIN)
+        if int(fits.item()):
+            break
+        if args.spp <= 16:
+            raise SystemExit("path state does not fit the GPU even at 16 spp per step")
+        args.spp //= 2
+    d_sum.zero_()
+    torch.cuda.synchronize()
 
     def sync():
         torch.cuda.synchronize()
