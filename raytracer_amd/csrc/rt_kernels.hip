@@ -645,7 +645,7 @@ struct rt_context {
     size_t pm_cap = 0;
     std::vector<hipEvent_t> events;
     // k_extend thresholds (lanes of a wave): refill once this many lanes are out of work, test leaves once this many wait
-    uint32_t tune_refill = 48, tune_leaf = 32;
+    uint32_t tune_refill = 44, tune_leaf = 36;
 };
 
 namespace {
