@@ -292,7 +292,26 @@ template <class XiFn>
 RT_HD bool rt_medium_t(const DScene& sc, const RtMedium& m, const Ray& r, double t_min, double t_max, const XiFn& xi,
                        double& t_out) {
     double t1 = 0.0, t2 = 0.0;
-    {   // boundary.hit(r, -inf, inf) then boundary.hit(r, rec1.t + 0.0001, inf) (constant_medium.rs:29-34); written as a
+    if (RT_REF_TYPE(m.boundary) == RT_REF_SPHERE) {
+        // The two boundary tests on a plain sphere are Sphere::hit (sphere.rs:34-64) twice on the same ray: same
+        // discriminant, same two quotients, only the range differs - computed once, compared twice.
+        const RtSphere s = sc.spheres[RT_REF_INDEX(m.boundary)];
+        const V3 oc = r.o - v3(s.cx, s.cy, s.cz);
+        const double a = v3_sqlen(r.d);
+        const double half_b = v3_dot(r.d, oc);
+        const double c = v3_sqlen(oc) - s.r * s.r;
+        const double delta = half_b * half_b - a * c;
+        if (!(delta > 0.0)) return false;
+        const double root = sqrt(delta);
+        const double q0 = (-half_b - root) / a, q1 = (-half_b + root) / a;
+        if (q0 > -RT_INF && q0 < RT_INF) t1 = q0;
+        else if (q1 > -RT_INF && q1 < RT_INF) t1 = q1;
+        else return false;
+        const double lo = t1 + 0.0001;
+        if (q0 > lo && q0 < RT_INF) t2 = q0;
+        else if (q1 > lo && q1 < RT_INF) t2 = q1;
+        else return false;
+    } else {   // boundary.hit(r, -inf, inf) then boundary.hit(r, rec1.t + 0.0001, inf) (constant_medium.rs:29-34); written as a
         // loop so that the boundary test is instantiated once
         double lo = -RT_INF, t = 0.0;
 #pragma unroll 1
