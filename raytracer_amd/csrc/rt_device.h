@@ -623,15 +623,14 @@ RT_HD HitRec rt_reconstruct(const DScene& sc, const Ray& wray, const RtHitLite& 
     }
 
     rec.p = ray_at(r, h.t);
-    if (type == RT_REF_SPHERE) {
-        const RtSphere s = sc.spheres[idx];
-        V3 outward = (rec.p - v3(s.cx, s.cy, s.cz)) / s.r;
+    if (type == RT_REF_SPHERE || type == RT_REF_MSPHERE) { // sphere.rs:57-61, moving_sphere.rs:63-66: (p - centre) / radius
+        V3 centre;
+        double radius;
+        if (type == RT_REF_SPHERE) { const RtSphere s = sc.spheres[idx]; centre = v3(s.cx, s.cy, s.cz); radius = s.r; }
+        else { const RtMSphere s = sc.mspheres[idx]; centre = rt_msphere_center(s, r.tm); radius = s.r; }
+        V3 outward = (rec.p - centre) / radius;
         rt_set_face_normal(rec, r.d, outward);
-        if (want_uv) rt_sphere_uv(outward, rec.u, rec.v);
-    } else if (type == RT_REF_MSPHERE) {
-        const RtMSphere s = sc.mspheres[idx];
-        V3 outward = (rec.p - rt_msphere_center(s, r.tm)) / s.r;
-        rt_set_face_normal(rec, r.d, outward);
+        if (want_uv && type == RT_REF_SPHERE) rt_sphere_uv(outward, rec.u, rec.v);
     } else if (type == RT_REF_RECT || type == RT_REF_BOX) {
         RtRect q;
         if (type == RT_REF_RECT) q = sc.rects[idx]; else q = rt_box_face(sc.boxes[idx], h.aux);
@@ -811,19 +810,28 @@ RT_HD ShadeOut rt_shade_as(const DScene& sc, const RtMaterial& m, const Ray& r_i
     o.scattered.d = v3(0.0, 0.0, 0.0);
     o.scattered.tm = 0.0;
     o.did_scatter = false;
-    switch (MAT < RT_MAT_COUNT ? MAT : m.type) {
-    case RT_MAT_LAMBERTIAN: { // material.rs:41-59
-        V3 scatter_direction = rec.normal + rt_random_unit_vector(smp);
+    const uint32_t type = MAT < RT_MAT_COUNT ? MAT : m.type;
+    // What several materials need is computed once, in front of the switch: lanes of a wave that hold different
+    // materials then run one rejection loop together instead of one per material in turn.
+    V3 in_sphere = v3(0.0, 0.0, 0.0), unit_in = v3(0.0, 0.0, 0.0);
+    if (type == RT_MAT_LAMBERTIAN || type == RT_MAT_METAL || type == RT_MAT_ISOTROPIC) in_sphere = rt_random_in_unit_sphere(smp);
+    if (type == RT_MAT_METAL || type == RT_MAT_DIELECTRIC) unit_in = v3_unit(r_in.d);
+    V3 colour = v3(0.0, 0.0, 0.0); // Texture::value of the material's texture (Lambertian / Isotropic albedo, DiffuseLight emit)
+    if (type == RT_MAT_LAMBERTIAN || type == RT_MAT_DIFFUSE_LIGHT || type == RT_MAT_ISOTROPIC)
+        colour = SOLID ? rt_tex_solid_value(sc, m.tex) : rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+    switch (type) {
+    case RT_MAT_LAMBERTIAN: { // material.rs:41-59; random_unit_vector = unit_vector(random_in_unit_sphere), vec3.rs:82-84
+        V3 scatter_direction = rec.normal + v3_unit(in_sphere);
         if (v3_near_zero(scatter_direction)) scatter_direction = rec.normal;
         o.scattered.o = rec.p; o.scattered.d = scatter_direction; o.scattered.tm = r_in.tm;
-        o.attenuation = SOLID ? rt_tex_solid_value(sc, m.tex) : rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+        o.attenuation = colour;
         o.did_scatter = true;
         break;
     }
     case RT_MAT_METAL: { // material.rs:80-97
-        V3 reflected = v3_reflect(v3_unit(r_in.d), rec.normal);
+        V3 reflected = v3_reflect(unit_in, rec.normal);
         o.scattered.o = rec.p;
-        o.scattered.d = reflected + rt_random_in_unit_sphere(smp) * m.p[3];
+        o.scattered.d = reflected + in_sphere * m.p[3];
         o.scattered.tm = r_in.tm;
         o.attenuation = v3(m.p[0], m.p[1], m.p[2]);
         o.did_scatter = v3_dot(o.scattered.d, rec.normal) > 0.0;
@@ -833,7 +841,7 @@ RT_HD ShadeOut rt_shade_as(const DScene& sc, const RtMaterial& m, const Ray& r_i
         o.attenuation = v3(1.0, 1.0, 1.0);
         const double ir = m.p[0];
         double refraction_ratio = rec.front_face ? 1.0 / ir : ir;
-        V3 unit_direction = v3_unit(r_in.d);
+        V3 unit_direction = unit_in;
         double cos_theta = v3_dot(-unit_direction, rec.normal);
         if (cos_theta > 1.0) cos_theta = 1.0;
         double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
@@ -848,12 +856,12 @@ RT_HD ShadeOut rt_shade_as(const DScene& sc, const RtMaterial& m, const Ray& r_i
         break;
     }
     case RT_MAT_DIFFUSE_LIGHT: { // material.rs:191-204: both faces emit
-        o.emitted = (SOLID ? rt_tex_solid_value(sc, m.tex) : rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p)) * m.p[0];
+        o.emitted = colour * m.p[0];
         break;
     }
     case RT_MAT_ISOTROPIC: { // material.rs:219-231: direction is not normalised
-        o.scattered.o = rec.p; o.scattered.d = rt_random_in_unit_sphere(smp); o.scattered.tm = r_in.tm;
-        o.attenuation = SOLID ? rt_tex_solid_value(sc, m.tex) : rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+        o.scattered.o = rec.p; o.scattered.d = in_sphere; o.scattered.tm = r_in.tm;
+        o.attenuation = colour;
         o.did_scatter = true;
         break;
     }
