@@ -523,6 +523,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_main(DScene sc, PassInfo pi,
                     const HitRec rec = rt_reconstruct(sc, r, h, false);
                     const Sampler smp = slot_sampler(pi, id, it);
                     const ShadeOut o = rt_shade_as<RT_MAT_COUNT, true>(sc, m, r, rec, smp);
+                    if (m.type == RT_MAT_DIELECTRIC) end = 1u; // glass keeps company with the media (one of them fills a glass sphere)
                     if (m.type == RT_MAT_DIFFUSE_LIGHT) { // the only material whose emitted() is not black
                         rad[0] += t.r * o.emitted.x;
                         rad[1] += t.g * o.emitted.y;
