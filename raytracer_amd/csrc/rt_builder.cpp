@@ -993,7 +993,13 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     for (const MatRec& m : mats) {
         RtMaterial d;
         d.type = m.type; d.tex = (uint32_t)std::max(0, m.tex);
+        d.tex_type = RT_TEX_SOLID; d.pad = 0;
         for (int i = 0; i < 4; ++i) d.p[i] = m.p[i];
+        if ((m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_DIFFUSE_LIGHT || m.type == RT_MAT_ISOTROPIC) && m.tex >= 0 && (size_t)m.tex < texs.size()) {
+            const TexRec& t = texs[(size_t)m.tex];
+            d.tex_type = t.type;
+            if (t.type == RT_TEX_SOLID) { d.p[1] = t.p[0]; d.p[2] = t.p[1]; d.p[3] = t.p[2]; }
+        }
         dmats.push_back(d);
     }
     std::vector<RtTexture> dtex;

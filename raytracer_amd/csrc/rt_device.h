@@ -818,7 +818,7 @@ RT_HD ShadeOut rt_shade_as(const DScene& sc, const RtMaterial& m, const Ray& r_i
     if (type == RT_MAT_METAL || type == RT_MAT_DIELECTRIC) unit_in = v3_unit(r_in.d);
     V3 colour = v3(0.0, 0.0, 0.0); // Texture::value of the material's texture (Lambertian / Isotropic albedo, DiffuseLight emit)
     if (type == RT_MAT_LAMBERTIAN || type == RT_MAT_DIFFUSE_LIGHT || type == RT_MAT_ISOTROPIC)
-        colour = SOLID ? rt_tex_solid_value(sc, m.tex) : rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+        colour = SOLID ? v3(m.p[1], m.p[2], m.p[3]) : rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p);
     switch (type) {
     case RT_MAT_LAMBERTIAN: { // material.rs:41-59; random_unit_vector = unit_vector(random_in_unit_sphere), vec3.rs:82-84
         V3 scatter_direction = rec.normal + v3_unit(in_sphere);

@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_main(DScene sc, PassInfo pi,
                 else mi = sc.media[idx].material;
                 const RtMaterial m = sc.materials[mi];
                 const bool textured = m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_DIFFUSE_LIGHT || m.type == RT_MAT_ISOTROPIC;
-                const uint32_t bucket = rt_bucket_of(m.type, textured ? sc.textures[m.tex].type : (uint32_t)RT_TEX_SOLID);
+                const uint32_t bucket = rt_bucket_of(m.type, textured ? m.tex_type : (uint32_t)RT_TEX_SOLID);
                 if (!rt_bucket_solid(bucket) && bucket != RT_BUCKET_METAL && bucket != RT_BUCKET_DIELECTRIC) {
                     later[0] = bucket;
                 } else {

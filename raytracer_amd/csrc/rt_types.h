@@ -10,7 +10,7 @@
 #include <stdint.h>
 
 #define RT_BLOB_MAGIC 0x31425452u /* "RTB1" little endian */
-#define RT_BLOB_VERSION 10u
+#define RT_BLOB_VERSION 11u
 
 // ---- tagged references -------------------------------------------------------------------------
 enum RtRefType : uint32_t {
@@ -100,8 +100,10 @@ enum RtBucket : uint32_t {
 };
 struct RtMaterial {
     uint32_t type;
-    uint32_t tex;     // Lambertian/Isotropic albedo, DiffuseLight emit
-    double p[4];      // Metal: albedo rgb + fuzz; Dielectric: p[0] = ir; DiffuseLight: p[0] = k
+    uint32_t tex;      // Lambertian/Isotropic albedo, DiffuseLight emit
+    uint32_t tex_type; // type of that texture (RT_TEX_SOLID for materials without one): shading decides where a hit goes without reading the texture
+    uint32_t pad;
+    double p[4];       // Metal: albedo rgb + fuzz; Dielectric: p[0] = ir; DiffuseLight: p[0] = k; Lambertian/Isotropic/DiffuseLight over a SolidColor: p[1..3] = its rgb
 };
 
 enum RtTextureType : uint32_t { RT_TEX_SOLID = 0, RT_TEX_CHECKER = 1, RT_TEX_NOISE = 2, RT_TEX_IMAGE = 3 };
