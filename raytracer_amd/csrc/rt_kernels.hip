@@ -664,7 +664,10 @@ int ctx_fail(rt_context* c, int code, const char* what, hipError_t e = hipSucces
 #define RT_HIP(call, what)                                                   \
     do {                                                                     \
         hipError_t e__ = (call);                                             \
-        if (e__ != hipSuccess) return ctx_fail(ctx, e__ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_NO_DEVICE, what, e__); \
+        if (e__ != hipSuccess) {                                             \
+            (void)hipGetLastError(); /* the error is reported through the return code, not left behind for the next HIP user of the process */ \
+            return ctx_fail(ctx, e__ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_NO_DEVICE, what, e__); \
+        }                                                                    \
     } while (0)
 
 int parse_header(rt_context* ctx, const RtBlobHeader& h, size_t nbytes) {
@@ -718,9 +721,17 @@ int ensure_paths(rt_context* ctx, size_t paths, uint32_t max_depth) {
         if (ctx->hit) hipFree(ctx->hit);
         if (ctx->u32pool) hipFree(ctx->u32pool);
         ctx->f64pool = nullptr; ctx->hit = nullptr; ctx->u32pool = nullptr; ctx->cap_paths = 0;
-        RT_HIP(hipMalloc((void**)&ctx->f64pool, paths * (2 * sizeof(PathRay) + 2 * sizeof(PathThr) + 3 * sizeof(double))), "hipMalloc path state");
-        RT_HIP(hipMalloc((void**)&ctx->hit, paths * sizeof(RtHitLite)), "hipMalloc hit records");
-        RT_HIP(hipMalloc((void**)&ctx->u32pool, paths * RT_BUCKET_COUNT * sizeof(uint32_t)), "hipMalloc queues");
+        hipError_t e = hipMalloc((void**)&ctx->f64pool, paths * (2 * sizeof(PathRay) + 2 * sizeof(PathThr) + 3 * sizeof(double)));
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->hit, paths * sizeof(RtHitLite));
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->u32pool, paths * RT_BUCKET_COUNT * sizeof(uint32_t));
+        if (e != hipSuccess) { // all or nothing: a caller that retries with a smaller pass must find the memory free
+            (void)hipGetLastError();
+            if (ctx->f64pool) hipFree(ctx->f64pool);
+            if (ctx->hit) hipFree(ctx->hit);
+            if (ctx->u32pool) hipFree(ctx->u32pool);
+            ctx->f64pool = nullptr; ctx->hit = nullptr; ctx->u32pool = nullptr;
+            return ctx_fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_NO_DEVICE, "hipMalloc path state", e);
+        }
         ctx->cap_paths = paths;
     }
     const size_t need = (size_t)(max_depth + 2) * RT_COUNTER_STRIDE;
