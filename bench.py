@@ -190,6 +190,11 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "extend_hbm_traffic.json")
         if os.path.exists(pmc_path):
             traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+        valu = {}
+        sq_path = os.path.join(ROOT, "profiles", "sq_counters.json")  # rocprofv3 --pmc SQ_* passes (tools/sq_summary.py)
+        if os.path.exists(sq_path):
+            sq = json.load(open(sq_path)).get("k_extend_tree", {})
+            valu = {"valu_busy": sq.get("valu_busy"), "valu_lane_use": sq.get("lane_use")}
         out = {
             "metric": "rays_per_sec", "value": segments / elapsed, "unit": "rays/s",
             "samples_per_sec": samples / elapsed,
@@ -207,7 +212,7 @@ def main():
                 "kernel": "k_extend_tree", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_segment": EXTEND_BYTES_PER_SEGMENT, "segments_per_launch": seg_per_launch,
-                "avg_launch_ms": avg_ms, "launches": int(stats.extend_launches),
+                "avg_launch_ms": avg_ms, "launches": int(stats.extend_launches), **valu,
                 "note": "cache-resident scene: the kernel is bound by f64 VALU issue and latency under divergence, "
                         "not by HBM; the HBM figure is the compulsory path-state traffic only",
             },
