@@ -724,6 +724,11 @@ RT_HD uint64_t rt_sat_usize(double v) {
     if (v >= 18446744073709551615.0) return UINT64_MAX;
     return (uint64_t)v;
 }
+// NoiseTexture::value (texture.rs:73-79)
+RT_HD V3 rt_tex_noise_value(const DScene& sc, const RtTexture& t, V3 p) {
+    double s = 0.5 * (1.0 + sin(t.p[0] * p.z + 10.0 * rt_perlin_turb(sc, t.a, p, 7)));
+    return v3(s, s, s);
+}
 // Texture::value for SolidColor / CheckerTexture / NoiseTexture / ImageTexture
 // (texture.rs:23-27, 46-54, 73-79, 105-127).
 RT_HD V3 rt_tex_value(const DScene& sc, uint32_t tex, double u, double v, V3 p) {
@@ -734,10 +739,7 @@ RT_HD V3 rt_tex_value(const DScene& sc, uint32_t tex, double u, double v, V3 p) 
         t = sc.textures[sines < 0.0 ? t.b : t.a];
     }
     if (t.type == RT_TEX_SOLID) return v3(t.p[0], t.p[1], t.p[2]);
-    if (t.type == RT_TEX_NOISE) {
-        double s = 0.5 * (1.0 + sin(t.p[0] * p.z + 10.0 * rt_perlin_turb(sc, t.a, p, 7)));
-        return v3(s, s, s);
-    }
+    if (t.type == RT_TEX_NOISE) return rt_tex_noise_value(sc, t, p);
     if (t.type == RT_TEX_IMAGE) {
         const uint64_t width = t.b, height = t.c;
         double u_ = rt_clamp(u, 0.0, 1.0);
@@ -767,7 +769,7 @@ RT_HD bool rt_material_reads_uv(const DScene& sc, const RtMaterial& m) {
 RT_HD uint32_t rt_bucket_of(uint32_t mat_type, uint32_t tex_type) {
     const uint32_t tex = tex_type == RT_TEX_SOLID ? 0u : 1u;
     switch (mat_type) {
-    case RT_MAT_LAMBERTIAN: return RT_BUCKET_LAMBERTIAN_SOLID + tex;
+    case RT_MAT_LAMBERTIAN: return tex_type == RT_TEX_NOISE ? (uint32_t)RT_BUCKET_LAMBERTIAN_NOISE : RT_BUCKET_LAMBERTIAN_SOLID + tex;
     case RT_MAT_METAL: return RT_BUCKET_METAL;
     case RT_MAT_DIELECTRIC: return RT_BUCKET_DIELECTRIC;
     case RT_MAT_DIFFUSE_LIGHT: return RT_BUCKET_LIGHT_SOLID + tex;
@@ -775,7 +777,7 @@ RT_HD uint32_t rt_bucket_of(uint32_t mat_type, uint32_t tex_type) {
     }
 }
 constexpr uint32_t rt_bucket_material(uint32_t bucket) {
-    return bucket <= RT_BUCKET_LAMBERTIAN_TEX ? RT_MAT_LAMBERTIAN : bucket == RT_BUCKET_METAL ? RT_MAT_METAL
+    return bucket <= RT_BUCKET_LAMBERTIAN_TEX || bucket == RT_BUCKET_LAMBERTIAN_NOISE ? RT_MAT_LAMBERTIAN : bucket == RT_BUCKET_METAL ? RT_MAT_METAL
          : bucket == RT_BUCKET_DIELECTRIC ? RT_MAT_DIELECTRIC : bucket <= RT_BUCKET_LIGHT_TEX ? RT_MAT_DIFFUSE_LIGHT : RT_MAT_ISOTROPIC;
 }
 constexpr bool rt_bucket_solid(uint32_t bucket) {
@@ -800,8 +802,9 @@ RT_HD double rt_reflectance(double cosine, double ref_idx) {
 }
 // emitted + scatter for the material of `rec`, the two calls ray_color makes at main.rs:62-66.
 // MAT = the material type when the caller knows it at compile time (the per-material shade kernels), which prunes
-// the other four bodies; RT_MAT_COUNT = decide from m.type at run time. SOLID = the caller knows the texture is a SolidColor.
-template <uint32_t MAT, bool SOLID = false>
+// the other four bodies; RT_MAT_COUNT = decide from m.type at run time. SOLID / NOISE = the caller knows the texture is a
+// SolidColor / a NoiseTexture.
+template <uint32_t MAT, bool SOLID = false, bool NOISE = false>
 RT_HD ShadeOut rt_shade_as(const DScene& sc, const RtMaterial& m, const Ray& r_in, const HitRec& rec, const Sampler& smp) {
     ShadeOut o;
     o.emitted = v3(0.0, 0.0, 0.0);
@@ -818,7 +821,7 @@ RT_HD ShadeOut rt_shade_as(const DScene& sc, const RtMaterial& m, const Ray& r_i
     if (type == RT_MAT_METAL || type == RT_MAT_DIELECTRIC) unit_in = v3_unit(r_in.d);
     V3 colour = v3(0.0, 0.0, 0.0); // Texture::value of the material's texture (Lambertian / Isotropic albedo, DiffuseLight emit)
     if (type == RT_MAT_LAMBERTIAN || type == RT_MAT_DIFFUSE_LIGHT || type == RT_MAT_ISOTROPIC)
-        colour = SOLID ? v3(m.p[1], m.p[2], m.p[3]) : rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+        colour = SOLID ? v3(m.p[1], m.p[2], m.p[3]) : NOISE ? rt_tex_noise_value(sc, sc.textures[m.tex], rec.p) : rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p);
     switch (type) {
     case RT_MAT_LAMBERTIAN: { // material.rs:41-59; random_unit_vector = unit_vector(random_in_unit_sphere), vec3.rs:82-84
         V3 scatter_direction = rec.normal + v3_unit(in_sphere);

@@ -34,7 +34,7 @@
 #define RT_BLOCK 256
 #define RT_TREE_BLOCK 1024 /* k_extend_tree: one workgroup per CU, so that the whole CU shares one LDS copy of the top of the tree */
 #define RT_COUNTER_STRIDE 16u /* per iteration: [0] paths entering it at the front of the arrays, [1+b] hits queued for shading bucket b, [RT_COUNTER_BACK] paths entering it at the back */
-#define RT_COUNTER_BACK 9u
+#define RT_COUNTER_BACK 15u
 
 // ---- device structures ------------------------------------------------------------------------------------
 // Path state. The paths alive at a bounce are DENSE: path number i of the bounce owns record i of the bounce's ray,
@@ -439,10 +439,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
             else if (ty == RT_REF_BOX) mi = sc.box_meta[idx].material;
             else mi = sc.media[idx].material;
             const RtMaterial m = sc.materials[mi];
-            const bool uv = (SOLID || MAT == RT_MAT_METAL || MAT == RT_MAT_DIELECTRIC) ? false : rt_material_reads_uv(sc, m);
+            const bool uv = (SOLID || MAT == RT_MAT_METAL || MAT == RT_MAT_DIELECTRIC || BUCKET == RT_BUCKET_LAMBERTIAN_NOISE) ? false : rt_material_reads_uv(sc, m);
             const HitRec rec = rt_reconstruct(sc, r, h, uv);
             const Sampler smp = slot_sampler(pi, id, it);
-            const ShadeOut o = rt_shade_as<MAT, SOLID>(sc, m, r, rec, smp);
+            const ShadeOut o = rt_shade_as<MAT, SOLID, BUCKET == RT_BUCKET_LAMBERTIAN_NOISE>(sc, m, r, rec, smp);
             if (MAT == RT_MAT_DIFFUSE_LIGHT) { // the only material whose emitted() is not black
                 double* rad = pb.rad + 3u * (size_t)id.slot;
                 rad[0] += t.r * o.emitted.x;
@@ -1070,6 +1070,7 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
             hipLaunchKernelGGL(k_shade_main, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);
             tm.end(a, 9);
             launch_shade<RT_BUCKET_LAMBERTIAN_TEX>(ctx, &local, pi, pb, qs, it, g_sh, tm);
+            launch_shade<RT_BUCKET_LAMBERTIAN_NOISE>(ctx, &local, pi, pb, qs, it, g_sh, tm);
             launch_shade<RT_BUCKET_LIGHT_TEX>(ctx, &local, pi, pb, qs, it, g_sh, tm);
             launch_shade<RT_BUCKET_ISOTROPIC_TEX>(ctx, &local, pi, pb, qs, it, g_sh, tm);
         }

@@ -96,7 +96,8 @@ enum RtMaterialType : uint32_t {
 enum RtBucket : uint32_t {
     RT_BUCKET_LAMBERTIAN_SOLID = 0, RT_BUCKET_LAMBERTIAN_TEX = 1, RT_BUCKET_METAL = 2, RT_BUCKET_DIELECTRIC = 3,
     RT_BUCKET_LIGHT_SOLID = 4, RT_BUCKET_LIGHT_TEX = 5, RT_BUCKET_ISOTROPIC_SOLID = 6, RT_BUCKET_ISOTROPIC_TEX = 7,
-    RT_BUCKET_COUNT = 8
+    RT_BUCKET_LAMBERTIAN_NOISE = 8, // Lambertian over a NoiseTexture: needs no u, v - the kernel that computes them (acos, atan2) needs 80 more registers
+    RT_BUCKET_COUNT = 9
 };
 struct RtMaterial {
     uint32_t type;
