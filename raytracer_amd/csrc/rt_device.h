@@ -56,6 +56,13 @@ RT_HD Ray rt_apply_inst(const RtInst& in, const Ray& r) {
     return o;
 }
 
+// The direction part of rt_apply_inst.
+RT_HD V3 rt_apply_inst_dir(const RtInst& in, V3 d) {
+    if ((in.op & RT_OP_MASK) == RT_OP_TRANSLATE) return d;
+    const double s = in.a, c = in.b;
+    return v3(c * d.x - s * d.z, d.y, s * d.x + c * d.z);
+}
+
 // The world ray carried down to the frame below instance `inst` (RT_NO_PARENT = world frame).
 RT_HD Ray rt_ray_to_level(const DScene& sc, const Ray& wray, int32_t inst) {
     int32_t chain[RT_MAX_CHAIN];
@@ -614,13 +621,10 @@ RT_HD HitRec rt_reconstruct(const DScene& sc, const Ray& wray, const RtHitLite& 
             if (p >= 0) p = sc.insts[p].parent_inst;
         }
     }
-    V3 dchild[RT_MAX_CHAIN]; // direction of the ray below instance chain[k]
     Ray r = wray;
 #pragma unroll
-    for (int k = RT_MAX_CHAIN - 1; k >= 0; --k) {
+    for (int k = RT_MAX_CHAIN - 1; k >= 0; --k)
         if (chain[k] >= 0) r = rt_apply_inst(sc.insts[chain[k]], r);
-        dchild[k] = r.d;
-    }
 
     rec.p = ray_at(r, h.t);
     if (type == RT_REF_SPHERE || type == RT_REF_MSPHERE) { // sphere.rs:57-61, moving_sphere.rs:63-66: (p - centre) / radius
@@ -652,9 +656,15 @@ RT_HD HitRec rt_reconstruct(const DScene& sc, const Ray& wray, const RtHitLite& 
     for (int k = 0; k < RT_MAX_CHAIN; ++k) {
         if (chain[k] >= 0) {
             const RtInst in = sc.insts[chain[k]];
+            // the direction of the ray below instance chain[k] (what hittable.rs:80, 176 pass to set_face_normal), worked
+            // out again from the world ray rather than kept from the way in: four kept directions are 24 registers
+            V3 dir = wray.d;
+#pragma unroll
+            for (int j = RT_MAX_CHAIN - 1; j >= k; --j)
+                if (chain[j] >= 0) dir = rt_apply_inst_dir(sc.insts[chain[j]], dir);
             if ((in.op & RT_OP_MASK) == RT_OP_TRANSLATE) {
                 rec.p = rec.p + v3(in.a, in.b, in.c);
-                rt_set_face_normal(rec, dchild[k], rec.normal);
+                rt_set_face_normal(rec, dir, rec.normal);
             } else {
                 const double s = in.a, c = in.b;
                 V3 p_ = rec.p, n_ = rec.normal;
@@ -670,7 +680,7 @@ RT_HD HitRec rt_reconstruct(const DScene& sc, const Ray& wray, const RtHitLite& 
                     n_.z = -s * n_.x + c * n_.z;
                 }
                 rec.p = p_;
-                rt_set_face_normal(rec, dchild[k], n_);
+                rt_set_face_normal(rec, dir, n_);
             }
         }
     }

@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
 // now - these are nearly all hits, their code is short, and Lambertian and Isotropic share the same rejection loop, so
 // mixing them in a wave costs little; a hit on a computed texture (Perlin noise, image, checker) is queued for the
 // k_shade kernel of its bucket, which would otherwise drag its registers and code through every wave.
-__global__ void __launch_bounds__(RT_BLOCK) k_shade_main(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it) {
+__global__ void __launch_bounds__(RT_BLOCK, 5) k_shade_main(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it) {
     __shared__ uint32_t scratch[2 * (RT_BLOCK / 64 + 1)];
     __shared__ uint32_t lds[RT_BUCKET_COUNT * (RT_BLOCK / 64)];
     uint32_t* ctr = qs.counters + it * RT_COUNTER_STRIDE;
