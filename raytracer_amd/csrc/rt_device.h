@@ -293,13 +293,19 @@ RT_HD bool rt_boundary_t(const DScene& sc, uint32_t ref, Ray r, double t_min, do
     }
 }
 
+// A source of medium uniforms may promise that every medium of the scene is bounded by a plain sphere
+// (static constexpr bool only_sphere_media = true): the general boundary test is then not compiled in. It costs
+// the traversal kernel 35 registers it does not have.
+template <class T, class = void> struct RtOnlySphereMedia { static constexpr bool value = false; };
+template <class T> struct RtOnlySphereMedia<T, decltype((void)T::only_sphere_media)> { static constexpr bool value = T::only_sphere_media; };
+
 // ConstantMedium::hit (constant_medium.rs:25-66). `xi(medium_index)` is the uniform the reference draws at :53; it is
 // only asked for once the ray is known to cross the boundary.
 template <class XiFn>
 RT_HD bool rt_medium_t(const DScene& sc, const RtMedium& m, const Ray& r, double t_min, double t_max, const XiFn& xi,
                        double& t_out) {
     double t1 = 0.0, t2 = 0.0;
-    if (RT_REF_TYPE(m.boundary) == RT_REF_SPHERE) {
+    if (RtOnlySphereMedia<XiFn>::value || RT_REF_TYPE(m.boundary) == RT_REF_SPHERE) {
         // The two boundary tests on a plain sphere are Sphere::hit (sphere.rs:34-64) twice on the same ray: same
         // discriminant, same two quotients, only the range differs - computed once, compared twice.
         const RtSphere s = sc.spheres[RT_REF_INDEX(m.boundary)];

@@ -123,7 +123,9 @@ struct CachedNodes {
 };
 
 struct PassInfo;
+template <bool ONLY_SPHERE_MEDIA>
 struct PhiloxXi { // the uniform a ConstantMedium draws (constant_medium.rs:53) for path `slot` at bounce `bounce`
+    static constexpr bool only_sphere_media = ONLY_SPHERE_MEDIA;
     const PassInfo* pi;
     PathId id;
     uint32_t bounce;
@@ -233,7 +235,8 @@ __device__ inline void store_ray(PathRay* rec, const Ray& r, PathId id) {
 __device__ inline Sampler slot_sampler(const PassInfo& pi, PathId id, uint32_t bounce) {
     return sampler_make(id.pixel, pi.sample_offset + id.slot % pi.S, bounce, pi.seed);
 }
-__device__ double PhiloxXi::operator()(uint32_t medium_index) const {
+template <bool ONLY_SPHERE_MEDIA>
+__device__ double PhiloxXi<ONLY_SPHERE_MEDIA>::operator()(uint32_t medium_index) const {
     return sampler_draw1(slot_sampler(*pi, id, bounce), RT_STREAM_MEDIUM0 + medium_index, 0u);
 }
 
@@ -278,7 +281,9 @@ __device__ unsigned long long g_phase[4][48];
 #else
 #define RT_PHASE_ADD(k, v) ((void)0)
 #endif
-template <bool EXACT_NODES> // false: the scene has no node whose box tests must reproduce the reference's f64 arithmetic
+// EXACT_NODES = false: the scene has no node whose box tests must reproduce the reference's f64 arithmetic.
+// SPHERE_MEDIA = true: every ConstantMedium of the scene is bounded by a plain sphere.
+template <bool EXACT_NODES, bool SPHERE_MEDIA>
 __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
                                                                uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_min,
                                                                uint32_t n_cached) {
@@ -346,7 +351,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
                     // the world entries every ray is tested against, by the lanes that just took a ray, in lock step
                     HeldRay held;
                     held.r = &s.r;
-                    PhiloxXi xi;
+                    PhiloxXi<SPHERE_MEDIA> xi;
                     xi.pi = &pi; xi.id = id; xi.bounce = it;
                     rt_extend_flat(sc, held, 0.001, s.best, xi, false);
                     s.slab = rt_slab_of(s.r, sc.node_extent);
@@ -385,7 +390,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
         if (active && s.cur != RT_REF_NONE && RT_REF_TYPE(s.cur) != RT_REF_NODE) {
             SlotRay ray_of;
             ray_of.rec = rays + path;
-            PhiloxXi xi;
+            PhiloxXi<SPHERE_MEDIA> xi;
             xi.pi = &pi; xi.id = id; xi.bounce = it;
             rt_trav_visit(sc, s, st, 0.001, xi, false, ray_of);
         }
@@ -627,6 +632,7 @@ struct rt_scene {
     DScene view;
     bool has_flat = true, has_tree = true; // whether the world holds plain primitives / BVHs at all
     uint32_t bucket_mask = 0;              // shading buckets some material of the scene falls into
+    bool sphere_media = true;              // every medium is bounded by a plain sphere (no instance, no other primitive)
 };
 
 struct rt_context {
@@ -899,6 +905,14 @@ static int upload_common(rt_context* ctx, const void* src, size_t nbytes, bool s
             s->bucket_mask |= 1u << rt_bucket_of(m.type, textured ? texs[m.tex].type : (uint32_t)RT_TEX_SOLID);
         }
     }
+    {
+        std::vector<RtMedium> media(s->hdr.media.count);
+        if (!media.empty())
+            e = hipMemcpy(media.data(), (const uint8_t*)src + s->hdr.media.offset, media.size() * sizeof(RtMedium),
+                          src_on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost);
+        if (e != hipSuccess) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_NO_DEVICE, "read media", e); }
+        for (const RtMedium& m : media) s->sphere_media = s->sphere_media && RT_REF_TYPE(m.boundary) == RT_REF_SPHERE;
+    }
     *out = s;
     return RT_OK;
 }
@@ -1026,9 +1040,11 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
     const uint32_t n_cached = (uint32_t)std::min<size_t>(sc->hdr.nodes.count, (ctx->lds_per_block - lds_stack_bytes - 16) / sizeof(RtNode));
     const size_t lds = lds_stack_bytes + (size_t)n_cached * sizeof(RtNode) + 16;
     const bool exact_nodes = sc->hdr.n_exact_nodes != 0u;
-    const void* k_extend = exact_nodes ? (const void*)k_extend_tree<true> : (const void*)k_extend_tree<false>;
+    typedef void (*ExtendKernel)(DScene, PassInfo, PathBufs, QueueSet, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
+    const ExtendKernel k_extend = exact_nodes ? (sc->sphere_media ? k_extend_tree<true, true> : k_extend_tree<true, false>)
+                                              : (sc->sphere_media ? k_extend_tree<false, true> : k_extend_tree<false, false>);
     if (lds > 65536)
-        RT_HIP(hipFuncSetAttribute(k_extend, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size of k_extend_tree");
+        RT_HIP(hipFuncSetAttribute((const void*)k_extend, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size of k_extend_tree");
     const uint32_t extend_blocks_per_cu = 1u;
     if (getenv("RT_DEBUG"))
         fprintf(stderr, "rt: lds_per_block %zu, stack_need %u, nodes %llu, cached %u, lds %zu\n", ctx->lds_per_block, stack_cap,
@@ -1059,12 +1075,8 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
         const uint32_t g_sh = grid_for(ctx, paths, 8);
         for (uint32_t it = 0; it < p->max_depth; ++it) {
             a = tm.begin();
-            if (exact_nodes)
-                hipLaunchKernelGGL(k_extend_tree<true>, dim3(g_ext), dim3(RT_TREE_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it,
-                                   stack_cap, ctx->tune_refill, ctx->tune_leaf, n_cached);
-            else
-                hipLaunchKernelGGL(k_extend_tree<false>, dim3(g_ext), dim3(RT_TREE_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it,
-                                   stack_cap, ctx->tune_refill, ctx->tune_leaf, n_cached);
+            hipLaunchKernelGGL(k_extend, dim3(g_ext), dim3(RT_TREE_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it, stack_cap,
+                               ctx->tune_refill, ctx->tune_leaf, n_cached);
             tm.end(a, 1);
             a = tm.begin();
             hipLaunchKernelGGL(k_shade_main, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);
