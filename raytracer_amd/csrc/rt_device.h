@@ -490,8 +490,7 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
         }
     } else {
         uint32_t leaf = s.cur;
-        bool moved = false;
-        int32_t back_to = RT_NO_PARENT;
+        Ray moved = s.r;
         if (type == RT_REF_INST) {
             RtInst in = sc.insts[idx];
             if ((in.op & RT_INST_LEAF) == 0u) { // a subtree in its own frame: enter it, leave through a POP marker
@@ -501,20 +500,17 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
                 s.cur = in.child;
                 return;
             }
-            // one primitive seen through instances: move the ray, test, take the frame's ray back - the box-test
-            // constants stay those of the frame
-            back_to = in.parent_inst;
-            moved = true;
+            // one primitive seen through instances: a moved copy of the ray is tested, the frame's ray and its box-test
+            // constants stay as they are
 #pragma unroll 1
             for (int guard = 0;; ++guard) {
-                s.r = rt_apply_inst(in, s.r);
+                moved = rt_apply_inst(in, moved);
                 leaf = in.child;
                 if (RT_REF_TYPE(leaf) != RT_REF_INST || guard >= RT_MAX_CHAIN) break;
                 in = sc.insts[RT_REF_INDEX(leaf)];
             }
         }
-        rt_test_leaf(sc, leaf, s.r, t_min, s.best, xi, skip_media);
-        if (moved) s.r = rt_ray_to_level(sc, world_ray(), back_to);
+        rt_test_leaf(sc, leaf, moved, t_min, s.best, xi, skip_media);
     }
     s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop();
 }
