@@ -655,7 +655,7 @@ struct rt_context {
     size_t pm_cap = 0;
     std::vector<hipEvent_t> events;
     // k_extend thresholds (lanes of a wave): refill once this many lanes are out of work, test leaves once this many wait
-    uint32_t tune_refill = 44, tune_leaf = 36;
+    uint32_t tune_refill = 0, tune_leaf = 0; // 0 = the defaults of rt_render_accumulate; RT_TUNE_REFILL / RT_TUNE_LEAF override
 };
 
 namespace {
@@ -1040,6 +1040,10 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
     const uint32_t n_cached = (uint32_t)std::min<size_t>(sc->hdr.nodes.count, (ctx->lds_per_block - lds_stack_bytes - 16) / sizeof(RtNode));
     const size_t lds = lds_stack_bytes + (size_t)n_cached * sizeof(RtNode) + 16;
     const bool exact_nodes = sc->hdr.n_exact_nodes != 0u;
+    // Scheduling thresholds of the traversal kernel, from sweeps (tools/tune.sh): trees walked nearest child first like
+    // earlier refills and leaf rounds than trees that replay the reference's order (long forced descents).
+    const uint32_t refill_min = ctx->tune_refill ? ctx->tune_refill : (exact_nodes ? 44u : 36u);
+    const uint32_t leaf_min = ctx->tune_leaf ? ctx->tune_leaf : (exact_nodes ? 36u : 30u);
     typedef void (*ExtendKernel)(DScene, PassInfo, PathBufs, QueueSet, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
     const ExtendKernel k_extend = exact_nodes ? (sc->sphere_media ? k_extend_tree<true, true> : k_extend_tree<true, false>)
                                               : (sc->sphere_media ? k_extend_tree<false, true> : k_extend_tree<false, false>);
@@ -1076,7 +1080,7 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
         for (uint32_t it = 0; it < p->max_depth; ++it) {
             a = tm.begin();
             hipLaunchKernelGGL(k_extend, dim3(g_ext), dim3(RT_TREE_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it, stack_cap,
-                               ctx->tune_refill, ctx->tune_leaf, n_cached);
+                               refill_min, leaf_min, n_cached);
             tm.end(a, 1);
             a = tm.begin();
             hipLaunchKernelGGL(k_shade_main, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);
