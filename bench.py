@@ -123,8 +123,8 @@ def main():
 
     W, H = info.width, info.height
     # One step = one pass of spp_step samples per pixel: the 50 bounces of a pass are 50 dependent rounds of launches, each
-    # with a latency floor, so a pass is made as large as the HBM takes (264 B of path state per path: 1024 spp of this
-    # GPU's share of 800x800 pixels = 173 GB). The first pass allocates; if it does not fit, every rank halves together.
+    # with a latency floor, so a pass is made as large as the HBM takes (232 B of path state per path: 1024 spp of this
+    # GPU's share of 800x800 pixels = 152 GB). The first pass allocates; if it does not fit, every rank halves together.
     while True:
         spp_step = args.spp * world
         params = api.params_from_info(info, seed=render_seed, tile=rdist.DEFAULT_TILE, tile_rank=rank, tile_world=world,

@@ -33,7 +33,7 @@
 
 #define RT_BLOCK 256
 #define RT_TREE_BLOCK 1024 /* k_extend_tree: one workgroup per CU, so that the whole CU shares one LDS copy of the top of the tree */
-#define RT_COUNTER_STRIDE 16u /* per iteration: [0] paths entering it at the front of the arrays, [1+b] hits queued for shading bucket b, [RT_COUNTER_BACK] paths entering it at the back */
+#define RT_COUNTER_STRIDE 16u /* per iteration: [0] paths entering it at the front of the arrays, [1+q] hits in queue q, [RT_COUNTER_BACK] paths entering it at the back */
 #define RT_COUNTER_BACK 15u
 
 // ---- device structures ------------------------------------------------------------------------------------
@@ -44,7 +44,7 @@
 // radiance array is indexed by slot, and it is written once per path, when the path ends.
 struct PathRay { double ox, oy, oz, dx, dy, dz, tm; uint32_t slot, pixel; }; // current ray (ray.rs:5-9) + whose it is: slot = local_pixel * S + sample, pixel = y * width + x
 struct PathId { uint32_t slot, pixel; };
-struct PathThr { double r, g, b, pad; };                                  // product of the attenuations so far (main.rs:70)
+struct PathThr { double r, g, b; };                                       // product of the attenuations so far (main.rs:70); 1, 1, 1 at the first bounce, where it is neither stored nor read
 struct PathBufs {
     PathRay* ray[2];  // [it & 1]: rays entering bounce it
     PathThr* thr[2];
@@ -57,8 +57,15 @@ struct PassInfo {
     double bg[3];
     uint64_t seed;
 };
+// The buckets that are shaded by a kernel of their own (the others are shaded where they are found, in k_shade_main)
+// have a queue each: queue number of a bucket, and how many there are.
+#define RT_QUEUES 4u
+constexpr uint32_t rt_bucket_queue(uint32_t bucket) {
+    return bucket == RT_BUCKET_LAMBERTIAN_TEX ? 0u : bucket == RT_BUCKET_LIGHT_TEX ? 1u : bucket == RT_BUCKET_ISOTROPIC_TEX ? 2u
+         : bucket == RT_BUCKET_LAMBERTIAN_NOISE ? 3u : 0xFFFFFFFFu;
+}
 struct QueueSet {
-    uint32_t* bucket;           // RT_BUCKET_COUNT queues of bucket_cap path numbers each, one per shading bucket
+    uint32_t* bucket;           // RT_QUEUES queues of bucket_cap path numbers each
     size_t bucket_cap;
     uint32_t* counters;         // (max_depth + 2) * RT_COUNTER_STRIDE
     uint32_t* error_flag;       // bit 0: traversal stack overflow
@@ -252,9 +259,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtCameraDev cam, PassInfo p
         PathId id;
         id.slot = slot; id.pixel = pixel;
         store_ray(pb.ray[0] + slot, r, id); // before the first bounce path number = slot
-        PathThr one;
-        one.r = 1.0; one.g = 1.0; one.b = 1.0; one.pad = 0.0;
-        pb.thr[0][slot] = one;
         pb.rad[3u * (size_t)slot] = 0.0; pb.rad[3u * (size_t)slot + 1u] = 0.0; pb.rad[3u * (size_t)slot + 2u] = 0.0;
     }
 }
@@ -413,8 +417,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
     constexpr uint32_t MAT = rt_bucket_material(BUCKET);
     constexpr bool SOLID = rt_bucket_solid(BUCKET);
     __shared__ uint32_t scratch[2 * (RT_BLOCK / 64 + 1)];
-    const uint32_t* bucket = qs.bucket + (size_t)BUCKET * qs.bucket_cap;
-    const uint32_t n = qs.counters[it * RT_COUNTER_STRIDE + 1u + BUCKET];
+    static_assert(rt_bucket_queue(BUCKET) < RT_QUEUES, "this bucket is shaded in k_shade_main");
+    const uint32_t* bucket = qs.bucket + (size_t)rt_bucket_queue(BUCKET) * qs.bucket_cap;
+    const uint32_t n = qs.counters[it * RT_COUNTER_STRIDE + 1u + rt_bucket_queue(BUCKET)];
     const PathRay* rays = pb.ray[it & 1u];
     const PathThr* thr = pb.thr[it & 1u];
     PathRay* next_rays = pb.ray[(it + 1u) & 1u];
@@ -430,12 +435,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
         Ray scattered;
         PathThr t;
         scattered.o = v3(0.0, 0.0, 0.0); scattered.d = v3(0.0, 0.0, 0.0); scattered.tm = 0.0;
-        t.r = 0.0; t.g = 0.0; t.b = 0.0; t.pad = 0.0;
+        t.r = 1.0; t.g = 1.0; t.b = 1.0;
         if (active) {
             const uint32_t path = bucket[i];
             const Ray r = load_ray(rays + path, id);
             const RtHitLite h = pb.hit[path];
-            t = thr[path];
+            if (it != 0u) t = thr[path];
             const uint32_t ty = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
             uint32_t mi;
             if (ty == RT_REF_SPHERE) mi = sc.sphere_meta[idx].material;
@@ -478,7 +483,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
 // k_shade kernel of its bucket, which would otherwise drag its registers and code through every wave.
 __global__ void __launch_bounds__(RT_BLOCK, 5) k_shade_main(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it) {
     __shared__ uint32_t scratch[2 * (RT_BLOCK / 64 + 1)];
-    __shared__ uint32_t lds[RT_BUCKET_COUNT * (RT_BLOCK / 64)];
+    __shared__ uint32_t lds[RT_QUEUES * (RT_BLOCK / 64)];
     uint32_t* ctr = qs.counters + it * RT_COUNTER_STRIDE;
     const LiveSet alive_paths = live_set(ctr, qs.bucket_cap);
     const uint32_t n = alive_paths.n();
@@ -499,11 +504,11 @@ __global__ void __launch_bounds__(RT_BLOCK, 5) k_shade_main(DScene sc, PassInfo 
         Ray scattered;
         PathThr t;
         scattered.o = v3(0.0, 0.0, 0.0); scattered.d = v3(0.0, 0.0, 0.0); scattered.tm = 0.0;
-        t.r = 0.0; t.g = 0.0; t.b = 0.0; t.pad = 0.0;
+        t.r = 1.0; t.g = 1.0; t.b = 1.0;
         if (base + threadIdx.x < n) {
             const RtHitLite h = pb.hit[i];
             const Ray r = load_ray(rays + i, id);
-            t = thr[i];
+            if (it != 0u) t = thr[i];
             end = RT_REF_TYPE(h.ref) == RT_REF_MEDIUM ? 1u : 0u; // scattered inside a medium: back of the arrays
             double* rad = pb.rad + 3u * (size_t)id.slot;
             if (h.ref == RT_REF_NONE) { // main.rs:56-58: return background; the path ends here
@@ -523,7 +528,7 @@ __global__ void __launch_bounds__(RT_BLOCK, 5) k_shade_main(DScene sc, PassInfo 
                 const bool textured = m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_DIFFUSE_LIGHT || m.type == RT_MAT_ISOTROPIC;
                 const uint32_t bucket = rt_bucket_of(m.type, textured ? m.tex_type : (uint32_t)RT_TEX_SOLID);
                 if (!rt_bucket_solid(bucket) && bucket != RT_BUCKET_METAL && bucket != RT_BUCKET_DIELECTRIC) {
-                    later[0] = bucket;
+                    later[0] = rt_bucket_queue(bucket);
                 } else {
                     const HitRec rec = rt_reconstruct(sc, r, h, false);
                     const Sampler smp = slot_sampler(pi, id, it);
@@ -544,7 +549,7 @@ __global__ void __launch_bounds__(RT_BLOCK, 5) k_shade_main(DScene sc, PassInfo 
             }
         }
         if (__syncthreads_or(later[0] != 0xFFFFFFFFu)) {
-            block_append_multi<1, RT_BUCKET_COUNT>(later, path, qs.bucket, qs.bucket_cap, ctr + 1u, lds);
+            block_append_multi<1, RT_QUEUES>(later, path, qs.bucket, qs.bucket_cap, ctr + 1u, lds);
             __syncthreads();
         }
         uint32_t j = block_reserve(alive, end, next_counter, next_counter + RT_COUNTER_BACK, scratch);
@@ -645,7 +650,7 @@ struct rt_context {
     size_t cap_paths = 0;
     uint8_t* f64pool = nullptr; // 2 x cap_paths PathRay, 2 x cap_paths PathThr, 3 x cap_paths doubles of radiance
     RtHitLite* hit = nullptr;
-    uint32_t* u32pool = nullptr; // RT_BUCKET_COUNT bucket queues, cap_paths each
+    uint32_t* u32pool = nullptr; // RT_QUEUES queues, cap_paths each
     uint32_t* counters = nullptr;
     size_t cap_counters = 0;
     uint32_t* error_flag = nullptr;
@@ -729,7 +734,7 @@ int ensure_paths(rt_context* ctx, size_t paths, uint32_t max_depth) {
         ctx->f64pool = nullptr; ctx->hit = nullptr; ctx->u32pool = nullptr; ctx->cap_paths = 0;
         hipError_t e = hipMalloc((void**)&ctx->f64pool, paths * (2 * sizeof(PathRay) + 2 * sizeof(PathThr) + 3 * sizeof(double)));
         if (e == hipSuccess) e = hipMalloc((void**)&ctx->hit, paths * sizeof(RtHitLite));
-        if (e == hipSuccess) e = hipMalloc((void**)&ctx->u32pool, paths * RT_BUCKET_COUNT * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->u32pool, paths * RT_QUEUES * sizeof(uint32_t));
         if (e != hipSuccess) { // all or nothing: a caller that retries with a smaller pass must find the memory free
             (void)hipGetLastError();
             if (ctx->f64pool) hipFree(ctx->f64pool);
