@@ -259,7 +259,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtCameraDev cam, PassInfo p
         PathId id;
         id.slot = slot; id.pixel = pixel;
         store_ray(pb.ray[0] + slot, r, id); // before the first bounce path number = slot
-        pb.rad[3u * (size_t)slot] = 0.0; pb.rad[3u * (size_t)slot + 1u] = 0.0; pb.rad[3u * (size_t)slot + 2u] = 0.0;
     }
 }
 
@@ -453,17 +452,16 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
             const HitRec rec = rt_reconstruct(sc, r, h, uv);
             const Sampler smp = slot_sampler(pi, id, it);
             const ShadeOut o = rt_shade_as<MAT, SOLID, BUCKET == RT_BUCKET_LAMBERTIAN_NOISE>(sc, m, r, rec, smp);
-            if (MAT == RT_MAT_DIFFUSE_LIGHT) { // the only material whose emitted() is not black
-                double* rad = pb.rad + 3u * (size_t)id.slot;
-                rad[0] += t.r * o.emitted.x;
-                rad[1] += t.g * o.emitted.y;
-                rad[2] += t.b * o.emitted.z;
-            }
             // a path that used its last bounce adds nothing more: ray_color(depth <= 0) is black (main.rs:52-54)
             if (o.did_scatter && it + 1u < pi.max_depth) {
                 alive = true;
                 scattered = o.scattered;
                 t.r *= o.attenuation.x; t.g *= o.attenuation.y; t.b *= o.attenuation.z;
+            } else { // the path ends here: what it adds to its pixel (only DiffuseLight's emitted() is not black) - written once per path
+                double* rad = pb.rad + 3u * (size_t)id.slot;
+                rad[0] = t.r * o.emitted.x;
+                rad[1] = t.g * o.emitted.y;
+                rad[2] = t.b * o.emitted.z;
             }
         }
         const uint32_t end = MAT == RT_MAT_ISOTROPIC ? 1u : 0u; // scattered inside a medium: back of the arrays
@@ -513,9 +511,9 @@ __global__ void __launch_bounds__(RT_BLOCK, 5) k_shade_main(DScene sc, PassInfo 
             double* rad = pb.rad + 3u * (size_t)id.slot;
             if (h.ref == RT_REF_NONE) { // main.rs:56-58: return background; the path ends here
                 const V3 bg = rt_background(pi.bg, pi.bg_mode, r);
-                rad[0] += t.r * bg.x;
-                rad[1] += t.g * bg.y;
-                rad[2] += t.b * bg.z;
+                rad[0] = t.r * bg.x;
+                rad[1] = t.g * bg.y;
+                rad[2] = t.b * bg.z;
             } else {
                 const uint32_t ty = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
                 uint32_t mi;
@@ -534,16 +532,15 @@ __global__ void __launch_bounds__(RT_BLOCK, 5) k_shade_main(DScene sc, PassInfo 
                     const Sampler smp = slot_sampler(pi, id, it);
                     const ShadeOut o = rt_shade_as<RT_MAT_COUNT, true>(sc, m, r, rec, smp);
                     if (m.type == RT_MAT_DIELECTRIC) end = 1u; // glass keeps company with the media (one of them fills a glass sphere)
-                    if (m.type == RT_MAT_DIFFUSE_LIGHT) { // the only material whose emitted() is not black
-                        rad[0] += t.r * o.emitted.x;
-                        rad[1] += t.g * o.emitted.y;
-                        rad[2] += t.b * o.emitted.z;
-                    }
                     // a path that used its last bounce adds nothing more: ray_color(depth <= 0) is black (main.rs:52-54)
                     if (o.did_scatter && it + 1u < pi.max_depth) {
                         alive = true;
                         scattered = o.scattered;
                         t.r *= o.attenuation.x; t.g *= o.attenuation.y; t.b *= o.attenuation.z;
+                    } else { // the path ends here (only DiffuseLight's emitted() is not black)
+                        rad[0] = t.r * o.emitted.x;
+                        rad[1] = t.g * o.emitted.y;
+                        rad[2] = t.b * o.emitted.z;
                     }
                 }
             }
