@@ -1075,10 +1075,10 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
         RT_HIP(hipMemsetAsync(ctx->counters, 0, n_counters * sizeof(uint32_t), ctx->stream), "clear counters");
         hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(RT_BLOCK), 0, ctx->stream, ctx->counters, (uint32_t)paths);
         size_t a = tm.begin();
-        hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, paths, 8)), dim3(RT_BLOCK), 0, ctx->stream, cd, pi, pb);
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, paths, 128)), dim3(RT_BLOCK), 0, ctx->stream, cd, pi, pb);
         tm.end(a, 0);
         const uint32_t g_ext = (uint32_t)std::max<size_t>(1, std::min<size_t>((paths + RT_TREE_BLOCK - 1) / RT_TREE_BLOCK, (size_t)ctx->n_cu * extend_blocks_per_cu));
-        const uint32_t g_sh = grid_for(ctx, paths, 8);
+        const uint32_t g_sh = grid_for(ctx, paths, 128); // (many more workgroups than fit at once: 8 per CU, each looping longer, cost k_shade_main 7 %)
         for (uint32_t it = 0; it < p->max_depth; ++it) {
             a = tm.begin();
             hipLaunchKernelGGL(k_extend, dim3(g_ext), dim3(RT_TREE_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it, stack_cap,
