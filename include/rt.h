@@ -51,6 +51,9 @@ const char* rt_builder_last_error(const rt_builder*);
  * times inside that interval - a render with a wider camera shutter, or a first-hit query outside it, returns
  * RT_ERR_UNSUPPORTED. With the bit set such nodes are replayed in the reference's form (same culling, slower) and
  * any time is accepted. Set before creating moving spheres.
+ * bit 3 = the world's tree is left to the device: rt_builder_compile puts the leaves under a balanced stand-in tree
+ * (correct, but slow to walk) instead of searching for good splits, and rt_scene_build_tree_device arranges them after the
+ * upload. Ignored together with bit 1 and for worlds that hold a BvhNode whose boxes do not bound their contents.
  * Default 0. */
 int rt_builder_set_flags(rt_builder*, uint32_t flags);
 
@@ -171,6 +174,20 @@ const char* rt_last_error(const rt_context*);
 int rt_scene_upload(rt_context*, const void* blob, size_t nbytes, rt_scene** out);             /* host blob */
 int rt_scene_upload_from_device(rt_context*, const void* d_blob, size_t nbytes, rt_scene** out); /* blob already in HBM (after an RCCL broadcast) */
 void rt_scene_free(rt_context*, rt_scene*);
+
+/* BvhNode::new (bvh.rs:15-66) for the world's tree, on the device: for a scene compiled with builder flag bit 3, arranges
+ * the leaves of the stand-in tree by a linear BVH build (Morton codes of the leaf centroids, radix sort, hierarchy and
+ * boxes in parallel) and writes the nodes over the stand-in's. Closest hits are those of any other tree over the same
+ * objects. RT_ERR_INVALID for a scene compiled without the flag or built already; RT_ERR_UNSUPPORTED when the tree would be taller than
+ * the traversal stack (the stand-in then stays, and the scene stays usable). No render may be in flight on the scene. */
+typedef struct {
+    uint32_t leaves, height;  /* objects under the tree; nodes on its longest root-to-leaf chain */
+    uint32_t key_bits;        /* Morton code bits used: 63, or 30 when 63 gave too tall a tree */
+    uint32_t stack_need;      /* traversal stack entries the scene needs with the new tree */
+    double ms_collect, ms_sort, ms_hierarchy, ms_refit, ms_commit; /* device time of the stages */
+    double seconds;           /* host wall clock of the call */
+} rt_tree_stats;
+int rt_scene_build_tree_device(rt_context*, rt_scene*, rt_tree_stats* stats /* nullable */);
 
 /* Hittable::hit of the world list for a batch of rays: out[i] = what world.hit(rays[i], tmin, tmax, rec)
  * (hittable_list.rs:40-53) leaves in rec. medium_xi: n * n_media uniforms, row i = the value each

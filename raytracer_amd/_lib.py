@@ -56,6 +56,12 @@ class rt_stats(C.Structure):
                 ("extend_segments", C.c_uint64)]
 
 
+class rt_tree_stats(C.Structure):
+    _fields_ = [("leaves", C.c_uint32), ("height", C.c_uint32), ("key_bits", C.c_uint32), ("stack_need", C.c_uint32),
+                ("ms_collect", C.c_double), ("ms_sort", C.c_double), ("ms_hierarchy", C.c_double), ("ms_refit", C.c_double),
+                ("ms_commit", C.c_double), ("seconds", C.c_double)]
+
+
 # every symbol include/rt.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _D3 = C.POINTER(C.c_double)
@@ -96,6 +102,7 @@ PROTOTYPES = {
     "rt_scene_upload": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(_P)]),
     "rt_scene_upload_from_device": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(_P)]),
     "rt_scene_free": (None, [_P, _P]),
+    "rt_scene_build_tree_device": (C.c_int, [_P, _P, C.POINTER(rt_tree_stats)]),
     "rt_trace_first_hit": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P]),
     "rt_generate_rays": (C.c_int, [_P, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_uint32, _P]),
     "rt_render_accumulate": (C.c_int, [_P, _P, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_uint32, C.c_uint32, _P,

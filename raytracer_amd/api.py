@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import RtError, lib, rt_camera, rt_params, rt_scene_info, rt_stats
+from ._lib import RtError, lib, rt_camera, rt_params, rt_scene_info, rt_stats, rt_tree_stats
 
 DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 RAY_DTYPE = np.dtype([(n, "<f8") for n in ("ox", "oy", "oz", "dx", "dy", "dz", "time", "tmin", "tmax")])
@@ -25,6 +25,10 @@ TEXTURE_FILES = {
     "raytracer/star5.jpeg": "star5_rgb8.npz",
     "raytracer/star6.jpeg": "star6_rgb8.npz",
 }
+
+
+# rt_builder_set_flags bits (include/rt.h)
+FLAG_BOOK_BBOX, FLAG_REFERENCE_TREE, FLAG_ANY_TIME, FLAG_DEVICE_TREE = 1, 2, 4, 8
 
 
 def load_texture(filename):
@@ -189,6 +193,12 @@ class Context:
         h = C.c_void_p()
         self._chk(lib.rt_scene_upload_from_device(self._c, d_ptr, nbytes, C.byref(h)))
         return Scene(self, h, nbytes)
+
+    def build_tree(self, scene):
+        """rt_scene_build_tree_device: arranges the world's tree of a scene compiled with FLAG_DEVICE_TREE on the GPU."""
+        st = rt_tree_stats()
+        self._chk(lib.rt_scene_build_tree_device(self._c, scene._h, C.byref(st)))
+        return st
 
     def trace_first_hit(self, scene, rays, medium_xi=None):
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)

@@ -38,7 +38,7 @@ def _csrc_files():
 
 
 def build_product(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("rt_kernels.hip", "rt_builder.cpp", "rt_scenes.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("rt_kernels.hip", "rt_tree_build.hip", "rt_builder.cpp", "rt_scenes.cpp")]
     if not force and _newer(PRODUCT_SO, _csrc_files()):
         return PRODUCT_SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

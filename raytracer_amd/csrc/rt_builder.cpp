@@ -506,6 +506,21 @@ Kid build_sah(std::vector<TNode>& tree, std::vector<SahItem>& items, size_t star
     k.node = me; k.box = box_union(a.box, b.box);
     return k;
 }
+
+// The stand-in for a tree that the device will build: the items as they come, halved down to single leaves
+// (a node over [start, end) splits at start + (end - start) / 2, which is what the device build walks by).
+Kid build_standin(std::vector<TNode>& tree, const std::vector<SahItem>& items, size_t start, size_t end) {
+    Kid k;
+    if (end - start == 1) { k.obj = items[start].obj; k.box = items[start].box; return k; }
+    const size_t mid = start + (end - start) / 2;
+    const int me = (int)tree.size();
+    tree.push_back(TNode());
+    const Kid a = build_standin(tree, items, start, mid);
+    const Kid b = build_standin(tree, items, mid, end);
+    tree[(size_t)me].kid[0] = a; tree[(size_t)me].kid[1] = b;
+    k.node = me; k.box = box_union(a.box, b.box);
+    return k;
+}
 }
 
 // A tree whose boxes all bound their contents: real boxes on both children, walked nearest first.
@@ -675,6 +690,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     std::vector<uint32_t> flat_refs, timed_refs;
     uint32_t need = 0;
     int run_rc = RT_OK;
+    uint32_t dt_root = RT_REF_NONE, dt_leaves = 0, dt_leaf_need = 0, dt_need_other = 0, dt_need_add = 0; // tree left to the device
     auto flatable = [&](int h) { // a primitive or medium under at most RT_MAX_CHAIN instances
         uint32_t chain = 0;
         while (objs[h].kind == OBJ_TRANSLATE || objs[h].kind == OBJ_ROTATE_Y) { h = objs[h].child; ++chain; }
@@ -813,7 +829,8 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         }
         if (!sah.empty()) {
             std::vector<TNode> tree;
-            Kid root = build_sah(tree, sah, 0, sah.size(), 0);
+            const bool defer = lock_step && (flags & RT_BLOB_FLAG_DEVICE_TREE) && !(flags & RT_BLOB_FLAG_REFERENCE_TREE) && sah.size() >= 2;
+            Kid root = defer ? build_standin(tree, sah, 0, sah.size()) : build_sah(tree, sah, 0, sah.size(), 0);
             if (root.node < 0) { // a single item still needs a node to carry its box
                 tree.push_back(TNode());
                 tree[0].kid[0] = root;
@@ -840,14 +857,17 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
                     const uint32_t c = emit(f, w.sub, parent, (uint32_t)w.chain.size(), ln);
                     if (c == RT_REF_NONE) return (uint32_t)RT_REF_NONE;
                     f.insts[(size_t)parent].child = c;
+                    dt_leaf_need = std::max(dt_leaf_need, ln);
                     return first;
                 }
                 const uint32_t r = emit(f, obj, RT_NO_PARENT, 0, ln);
                 if (handle_timed[(size_t)obj] && r != RT_REF_NONE) timed_refs.push_back(r);
+                dt_leaf_need = std::max(dt_leaf_need, ln);
                 return r;
             }, n);
             if (out.ref == RT_REF_NONE) { run_rc = error.empty() ? fail(RT_ERR_UNSUPPORTED, "empty scene") : RT_ERR_UNSUPPORTED; return out; }
             out.box = root.box;
+            if (defer) { dt_root = out.ref; dt_leaves = (uint32_t)sah.size(); dt_need_other = need; dt_need_add = (uint32_t)loose_refs.size(); }
             need = std::max(need, n);
         }
         for (size_t k = loose_refs.size(); k-- > 0;) { // T = { child 0: the entry, always entered; child 1: what was built so far }
@@ -981,6 +1001,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         for (RtInst& in : f.insts) remap(in.child);
         for (uint32_t& e : f.list_entries) remap(e);
         remap(tree_ref);
+        remap(dt_root);
     }
     const size_t biggest = std::max({f.nodes.size(), f.spheres.size(), f.mspheres.size(), f.rects.size(), f.boxes.size(), f.media.size(),
                                      f.insts.size(), f.list_entries.size()});
@@ -1059,6 +1080,8 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     hd.max_chain = f.max_chain;
     hd.flags = flags;
     hd.n_objects = (uint32_t)objs.size();
+    hd.device_tree_root = dt_root; hd.device_tree_leaves = dt_root != RT_REF_NONE ? dt_leaves : 0u;
+    hd.device_tree_leaf_need = dt_leaf_need; hd.device_tree_need_other = dt_need_other; hd.device_tree_need_add = dt_need_add;
     for (const RtNode& n : f.nodes) {
         if (n.pad[0] & RT_NODE_EXACT) hd.n_exact_nodes += 1u;
         const float* boxes[4] = {n.lo0, n.hi0, n.lo1, n.hi1};

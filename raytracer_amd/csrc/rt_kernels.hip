@@ -30,6 +30,7 @@
 #include "../../include/rt.h"
 #include "rt_builder.h"
 #include "rt_device.h"
+#include "rt_tree_build.h"
 
 #define RT_BLOCK 256
 #define RT_TREE_BLOCK 1024 /* k_extend_tree: one workgroup per CU, so that the whole CU shares one LDS copy of the top of the tree */
@@ -635,6 +636,7 @@ struct rt_scene {
     bool has_flat = true, has_tree = true; // whether the world holds plain primitives / BVHs at all
     uint32_t bucket_mask = 0;              // shading buckets some material of the scene falls into
     bool sphere_media = true;              // every medium is bounded by a plain sphere (no instance, no other primitive)
+    bool tree_built = false;               // rt_scene_build_tree_device has replaced the stand-in tree
 };
 
 struct rt_context {
@@ -925,6 +927,38 @@ void rt_scene_free(rt_context* ctx, rt_scene* s) {
     if (ctx) hipSetDevice(ctx->device);
     if (s->d_blob) hipFree(s->d_blob);
     delete s;
+}
+
+int rt_scene_build_tree_device(rt_context* ctx, rt_scene* sc, rt_tree_stats* stats) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!sc) return ctx_fail(ctx, RT_ERR_INVALID, "build_tree_device: null scene");
+    if (stats) memset(stats, 0, sizeof *stats);
+    const RtBlobHeader& h = sc->hdr;
+    if (!(h.flags & RT_BLOB_FLAG_DEVICE_TREE) || RT_REF_TYPE(h.device_tree_root) != RT_REF_NODE || h.device_tree_leaves < 1u)
+        return ctx_fail(ctx, RT_ERR_INVALID, "build_tree_device: the scene was not compiled with a tree left to the device (builder flag 8)");
+    if (sc->tree_built) return ctx_fail(ctx, RT_ERR_INVALID, "build_tree_device: the scene's tree has been built already");
+    RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    const auto t0 = std::chrono::steady_clock::now();
+    // stack entries: one per node on the way down, what the deepest leaf needs below it, one per node chained in front
+    const uint32_t fixed = h.device_tree_leaf_need + h.device_tree_need_add + 1u;
+    if (fixed >= RT_STACK_CAP) return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "build_tree_device: no stack left for a tree");
+    RtTreeBuildResult res;
+    std::string err;
+    const int rc = rt_tree_build_device(ctx->stream, (RtNode*)((uint8_t*)sc->d_blob + h.nodes.offset), (size_t)h.nodes.count,
+                                        RT_REF_INDEX(h.device_tree_root), h.device_tree_leaves, RT_STACK_CAP - fixed, &res, err);
+    if (rc != RT_OK) return ctx_fail(ctx, rc, err.c_str());
+    sc->tree_built = true;
+    if (h.device_tree_leaves >= 2u) {
+        const uint32_t need = std::max(h.device_tree_need_other, res.height + h.device_tree_leaf_need) + h.device_tree_need_add;
+        sc->hdr.stack_need = std::max(1u, need) + 1u;
+    }
+    if (stats) {
+        stats->leaves = h.device_tree_leaves; stats->height = res.height; stats->key_bits = res.key_bits; stats->stack_need = sc->hdr.stack_need;
+        stats->ms_collect = res.ms_collect; stats->ms_sort = res.ms_sort; stats->ms_hierarchy = res.ms_hierarchy;
+        stats->ms_refit = res.ms_refit; stats->ms_commit = res.ms_commit;
+        stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return RT_OK;
 }
 
 static int check_error_flag(rt_context* ctx) {

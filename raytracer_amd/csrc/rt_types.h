@@ -10,7 +10,7 @@
 #include <stdint.h>
 
 #define RT_BLOB_MAGIC 0x31425452u /* "RTB1" little endian */
-#define RT_BLOB_VERSION 11u
+#define RT_BLOB_VERSION 12u
 
 // ---- tagged references -------------------------------------------------------------------------
 enum RtRefType : uint32_t {
@@ -138,9 +138,21 @@ struct RtBlobHeader {
     uint64_t n_exact_nodes;    // nodes flagged RT_NODE_EXACT
     RtSection nodes, spheres, sphere_meta, mspheres, msphere_meta, rects, rect_meta, boxes, box_meta,
         media, insts, list_entries, materials, textures, perlin_vec, perlin_perm, texels;
+    // A world tree left for the device to build (RT_BLOB_FLAG_DEVICE_TREE). The compiler has put its leaves, in the order
+    // it met them, under a balanced stand-in tree: a node over leaves [s, e) has child 0 over [s, m) and child 1 over
+    // [m, e), m = s + (e - s) / 2, down to single leaves. The stand-in is valid (every box bounds what is below it) but
+    // groups leaves that have nothing to do with each other; the device build re-arranges the same leaves in the same
+    // node records.
+    uint32_t device_tree_root;   // NODE ref of the stand-in's root, RT_REF_NONE when there is nothing to build
+    uint32_t device_tree_leaves; // number of leaves below it
+    uint32_t device_tree_leaf_need; // most stack entries anything below one of its leaves needs
+    uint32_t device_tree_need_other; // stack entries the world's entries outside the tree need
+    uint32_t device_tree_need_add;   // nodes chained in front of the tree, one stack entry each
+    uint32_t pad_tail;
 };
 #define RT_BLOB_FLAG_BOOK_BBOX 1u      /* RotateY stores its rotated box (book behaviour) instead of the child's */
 #define RT_BLOB_FLAG_REFERENCE_TREE 2u /* every BvhNode keeps the reference's topology (random-axis median split) */
+#define RT_BLOB_FLAG_DEVICE_TREE 8u    /* the world's tree is a stand-in, to be rebuilt on the device after upload (rt_scene_build_tree_device) */
 #define RT_BLOB_FLAG_ANY_TIME 4u       /* rays may carry any time: a BvhNode over moving spheres is replayed in the reference's form instead of being rebuilt */
 
 // ---- render-time records -------------------------------------------------------------------------
