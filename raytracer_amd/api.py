@@ -264,6 +264,25 @@ def write_ppm(path, rgb8):
         f.write(rgb8.tobytes())
 
 
+def write_png(path, rgb8):
+    """8-bit RGB PNG (lossless stand-in for the reference's `img.save("output/test.jpg")`, main.rs:255), same row order as
+    write_ppm. One zlib stream, filter type 0 on every row."""
+    import struct
+    import zlib
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    assert rgb8.ndim == 3 and rgb8.shape[2] == 3
+    h, w = rgb8.shape[:2]
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    rows = np.concatenate([np.zeros((h, 1), dtype=np.uint8), rgb8.reshape(h, w * 3)], axis=1)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n")
+        f.write(chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)))
+        f.write(chunk(b"IDAT", zlib.compress(rows.tobytes(), 6)))
+        f.write(chunk(b"IEND", b""))
+
+
 def save_checkpoint(path, rgb_sum, samples_done, seed):
     """The linear radiance sums and how many samples per pixel they hold: enough to resume with Context.render_more."""
     np.savez(path, rgb_sum=np.asarray(rgb_sum, dtype=np.float64), samples_done=np.uint32(samples_done), seed=np.uint64(seed))

@@ -533,7 +533,7 @@ uint32_t rt_builder::emit_bvh(Flat& f, const ObjRec& o, int parent, uint32_t dep
         limit_time(o);
         std::vector<TNode> tree;
         Kid root;
-        if (flags & RT_BLOB_FLAG_REFERENCE_TREE) {
+        if ((flags & RT_BLOB_FLAG_REFERENCE_TREE) && !o.tree.empty()) {
             // the reference's topology (bvh.rs:15-66); a span-1 node (bvh.rs:33-35) holds its object once
             tree.resize(o.tree.size());
             for (size_t i = 0; i < o.tree.size(); ++i) {
@@ -952,6 +952,9 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         std::deque<uint32_t> frontier;
         std::vector<uint32_t> pending;
         auto expand = [&](uint32_t ref, auto&& sink) { // hands every node reachable from `ref` without passing through a node to sink
+            const uint32_t ty0 = RT_REF_TYPE(ref);
+            if (ty0 == RT_REF_NODE) { sink(RT_REF_INDEX(ref)); return; }
+            if (ty0 != RT_REF_INST && ty0 != RT_REF_LIST) return; // a primitive: nothing below it
             std::vector<uint32_t> todo(1, ref);
             while (!todo.empty()) {
                 const uint32_t r = todo.back(); todo.pop_back();
@@ -1347,9 +1350,22 @@ int rt_bvh(rt_builder* b, int list, double t0, double t1) {
     }
     ObjRec o; o.kind = OBJ_BVH; o.child = list; o.d[0] = t0; o.d[1] = t1;
     b->axis_log.clear();
-    if (b->build_bvh_node(o.tree, objects, keys, 0, objects.size(), t0, t1) < 0) return RT_ERR_PANIC;
-    o.box = o.tree[0].box;
     for (int m : objects) o.exact_bounds = o.exact_bounds && b->objs[m].exact_bounds;
+    // With the tree left to the device (flag bit 3) a BvhNode whose boxes all bound their contents is never emitted in
+    // the reference's shape - it is a set of objects and their bound - so the reference's build (a sort per level,
+    // bvh.rs:26-63) is skipped; what remains of it is the root's box (bvh.rs:55-64: the union of the members' boxes).
+    const bool shape_unused = o.exact_bounds && (b->flags & RT_BLOB_FLAG_DEVICE_TREE) && !(b->flags & RT_BLOB_FLAG_REFERENCE_TREE);
+    if (shape_unused) {
+        o.box = kEmptyBox;
+        for (int m : objects) {
+            AABB bb;
+            if (!b->bounding_box(m, t0, t1, bb)) return b->fail(RT_ERR_PANIC, "No bounding box in bvh_node constructor");
+            o.box = box_union(o.box, bb);
+        }
+    } else {
+        if (b->build_bvh_node(o.tree, objects, keys, 0, objects.size(), t0, t1) < 0) return RT_ERR_PANIC;
+        o.box = o.tree[0].box;
+    }
     int id = b->add_obj(std::move(o));
     // the axes drawn (bvh.rs:22), in construction order, so that a replay can rebuild the same tree
     append_fmt(b->log, "bvh %d %d %a %a ", id, list, t0, t1);

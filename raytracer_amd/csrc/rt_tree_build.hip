@@ -107,13 +107,19 @@ __global__ void __launch_bounds__(TB_BLOCK) k_tb_morton(const TbBox* __restrict_
     const uint32_t k = blockIdx.x * TB_BLOCK + threadIdx.x;
     if (k >= n) return;
     const TbBox b = leaf_box[k];
+    // one cell size for all three axes (the largest extent over 2^21): a flat scene is then not cut along its thin axis
+    // until the cells are as small as it is thin
+    float ext = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+        const float e = tb_unord(status[ST_CMAX + a]) - tb_unord(status[ST_CMIN + a]);
+        if (isfinite(e) && e > ext) ext = e;
+    }
     uint64_t q[3];
     for (int a = 0; a < 3; ++a) {
-        const float cmin = tb_unord(status[ST_CMIN + a]), cmax = tb_unord(status[ST_CMAX + a]);
-        const float ext = cmax - cmin;
+        const float cmin = tb_unord(status[ST_CMIN + a]);
         const float c = 0.5f * b.lo[a] + 0.5f * b.hi[a];
         float x = 0.0f;
-        if (ext > 0.0f && isfinite(ext) && isfinite(c)) x = (c - cmin) / ext * 2097152.0f;
+        if (ext > 0.0f && isfinite(c) && isfinite(cmin)) x = (c - cmin) / ext * 2097152.0f;
         x = fminf(fmaxf(x, 0.0f), 2097151.0f);
         q[a] = (uint64_t)((uint32_t)x >> (21u - bits));
     }

@@ -267,3 +267,13 @@ def test_ppm_writer_and_checkpoint_round_trip(tmp_path):
     assert got.tobytes() == s.tobytes() and done == 12 and seed == 0x5EED0002
     # the pixel conversion of main.rs:172-189: sqrt(sum / spp) clamped to 0.999, times 255.999, truncated
     assert api.tonemap(np.array([[[0.0, 4.0, 1.0]]]), 4).tolist() == [[[0, 255, 127]]]
+
+
+def test_png_writer_round_trip(tmp_path):
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (9, 13, 3), dtype=np.uint8)
+    api.write_png(str(tmp_path / "a.png"), img)
+    with Image.open(str(tmp_path / "a.png")) as im:
+        assert im.mode == "RGB" and im.size == (13, 9)
+        assert np.array_equal(np.asarray(im), img)
