@@ -1356,6 +1356,15 @@ int rt_bvh(rt_builder* b, int list, double t0, double t1) {
     // bvh.rs:26-63) is skipped; what remains of it is the root's box (bvh.rs:55-64: the union of the members' boxes).
     const bool shape_unused = o.exact_bounds && (b->flags & RT_BLOB_FLAG_DEVICE_TREE) && !(b->flags & RT_BLOB_FLAG_REFERENCE_TREE);
     if (shape_unused) {
+        // the axis draws of the skipped constructor calls (bvh.rs:22, one per BvhNode::new) are still made, in the same
+        // order: what the scene code draws afterwards (Perlin tables, the next tree) must not depend on the flag
+        std::vector<std::pair<size_t, bool>> todo(1, std::make_pair(objects.size(), false));
+        while (!todo.empty()) { // pre-order, left before right, as the recursion of bvh.rs:45-52
+            const size_t span = todo.back().first;
+            todo.pop_back();
+            b->axis_log.push_back((char)('0' + b->rng.irange(0, 3)));
+            if (span > 2) { todo.push_back(std::make_pair(span - span / 2, false)); todo.push_back(std::make_pair(span / 2, false)); }
+        }
         o.box = kEmptyBox;
         for (int m : objects) {
             AABB bb;

@@ -67,3 +67,12 @@ def test_flag_is_ignored_where_the_tree_must_keep_the_reference_order():
     assert tail(blob)[:2] == (0, 0)
     _, _, blob, _ = util.build_scene("final_scene", flags=api.FLAG_DEVICE_TREE | api.FLAG_REFERENCE_TREE)
     assert tail(blob)[:2] == (0, 0)
+
+
+@pytest.mark.parametrize("name", ["final_scene", "random_scene", "stress_volume"])
+def test_the_flag_does_not_change_the_scene(name):
+    """rt_bvh skips the reference's build under the flag but still makes its axis draws (bvh.rs:22): Perlin tables and
+    whatever else the scene code draws afterwards come out the same, and so does the constructor log."""
+    _, _, _, d0 = util.build_scene(name)
+    _, _, _, d1 = util.build_scene(name, flags=api.FLAG_DEVICE_TREE)
+    assert d0.replace(b"flags 0\n", b"") == d1.replace(b"flags 8\n", b"")
