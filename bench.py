@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step (halved until the path state fits the GPU)")
+    ap.add_argument("--spp", type=int, default=1536, help="samples per pixel per GPU per step (reduced - 1536, 1024, 512, ... - until the path state fits the GPU)")
     ap.add_argument("--scene", default="final_scene")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     args = ap.parse_args()
@@ -123,8 +123,8 @@ def main():
 
     W, H = info.width, info.height
     # One step = one pass of spp_step samples per pixel: the 50 bounces of a pass are 50 dependent rounds of launches, each
-    # with a latency floor, so a pass is made as large as the HBM takes (232 B of path state per path: 1024 spp of this
-    # GPU's share of 800x800 pixels = 152 GB). The first pass allocates; if it does not fit, every rank halves together.
+    # with a latency floor, so a pass is made as large as the HBM takes (232 B of path state per path: 1536 spp of this
+    # GPU's share of 800x800 pixels = 228 GB). The first pass allocates; if it does not fit, every rank steps down together.
     while True:
         spp_step = args.spp * world
         params = api.params_from_info(info, seed=render_seed, tile=rdist.DEFAULT_TILE, tile_rank=rank, tile_world=world,
@@ -144,7 +144,7 @@ def main():
             break
         if args.spp <= 16:
             raise SystemExit("path state does not fit the GPU even at 16 spp per step")
-        args.spp //= 2
+        args.spp = args.spp * 2 // 3 if args.spp % 3 == 0 else args.spp // 2
     d_sum.zero_()
     torch.cuda.synchronize()
 

@@ -283,6 +283,16 @@ def write_png(path, rgb8):
         f.write(chunk(b"IEND", b""))
 
 
+def write_jpeg(path, rgb8, quality=75):
+    """`img.save("output/test.jpg")` (main.rs:255) through Pillow's baseline encoder at the `image` crate's default
+    quality. The bytes are not those of the crate's own encoder (different Huffman tables and rounding; nothing in the
+    reference pins them); the decoded picture agrees to JPEG precision. Pillow is the one optional dependency here."""
+    from PIL import Image
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    assert rgb8.ndim == 3 and rgb8.shape[2] == 3
+    Image.fromarray(rgb8, "RGB").save(path, format="JPEG", quality=int(quality))
+
+
 def save_checkpoint(path, rgb_sum, samples_done, seed):
     """The linear radiance sums and how many samples per pixel they hold: enough to resume with Context.render_more."""
     np.savez(path, rgb_sum=np.asarray(rgb_sum, dtype=np.float64), samples_done=np.uint32(samples_done), seed=np.uint64(seed))

@@ -277,3 +277,13 @@ def test_png_writer_round_trip(tmp_path):
     with Image.open(str(tmp_path / "a.png")) as im:
         assert im.mode == "RGB" and im.size == (13, 9)
         assert np.array_equal(np.asarray(im), img)
+
+
+def test_jpeg_writer(tmp_path):
+    Image = pytest.importorskip("PIL.Image")
+    y, x = np.mgrid[0:48, 0:64]
+    img = np.stack([x * 4, y * 5, (x + y) * 2], axis=2).astype(np.uint8)      # smooth: JPEG keeps it within a few levels
+    api.write_jpeg(str(tmp_path / "a.jpg"), img)
+    with Image.open(str(tmp_path / "a.jpg")) as im:
+        assert im.format == "JPEG" and im.size == (64, 48)
+        assert np.abs(np.asarray(im.convert("RGB")).astype(int) - img.astype(int)).mean() < 3.0

@@ -24,7 +24,7 @@ segments = json.loads(line)["roofline"]["segments_per_launch"] * launches
 fetch, write = tot["FETCH_SIZE"] * 1024.0, tot["WRITE_SIZE"] * 1024.0
 out = {
     "kernel": "k_extend_tree",
-    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-include-regex k_extend_tree -- python3 tools/render_once.py --spp 1024 (separate passes)",
+    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-include-regex k_extend_tree -- python3 tools/render_once.py --spp 1536 (separate passes)",
     "launches": launches,
     "FETCH_SIZE_KB_sum": tot["FETCH_SIZE"],
     "WRITE_SIZE_KB_sum": tot["WRITE_SIZE"],
