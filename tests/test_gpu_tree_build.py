@@ -94,3 +94,28 @@ def test_scenes_without_a_tree_for_the_device(gpu_ctx):
     rep = util.first_hit_report(gpu_ctx.trace_first_hit(scene, rays, xi), osc.trace_first_hit(rays, xi))
     assert rep["prim_match"] >= 0.9999, rep                      # and the scene is as usable as ever
     scene.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scene_graphs_with_device_built_trees(gpu_ctx, seed):
+    """Random nestings of every hittable kind: the leaves handed to the device are then primitives, media, instanced
+    leaves and whole sub-trees alike. Worlds that must keep a reference-order tree leave nothing to build (-1)."""
+    for flags in (api.FLAG_DEVICE_TREE, api.FLAG_DEVICE_TREE | api.FLAG_ANY_TIME):
+        try:
+            b, world = util.random_scene_graph(seed, flags)
+            blob, desc = b.compile(world), b.describe(world)
+        except api.RtError as e:
+            assert e.code == -2
+            continue
+        osc = ck.OracleScene(desc, share_bvh_axes=True)
+        scene = gpu_ctx.upload(blob)
+        try:
+            gpu_ctx.build_tree(scene)
+        except api.RtError as e:
+            assert e.code == -1
+        rng = np.random.default_rng(1000 + seed)
+        rays = util.random_rays(rng, 4000, any_time=bool(flags & api.FLAG_ANY_TIME))
+        xi = rng.random((len(rays), osc.n_media)) if osc.n_media else None
+        rep = util.first_hit_report(gpu_ctx.trace_first_hit(scene, rays, xi), osc.trace_first_hit(rays, xi))
+        assert rep["prim_match"] >= 0.9995 and rep["t_rel_max"] <= 1e-5 and rep["t_bit_equal"] >= 0.95, (seed, flags, rep)
+        scene.close()
