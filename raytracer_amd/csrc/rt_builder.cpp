@@ -7,6 +7,7 @@
 #include "rt_builder.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -35,6 +36,64 @@ void append_fmt(std::string& s, const char* fmt, ...) {
     int n = vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     if (n > 0) s.append(buf, (size_t)std::min<int>(n, (int)sizeof buf - 1));
+}
+
+// The constructor log is kept as compact records and written out as text only when rt_builder_describe asks for it:
+// formatting a hexadecimal float per argument as the objects are created cost more than building them (a million
+// spheres: 4 of 5 seconds). A record is the format string's address (always a literal) followed by its arguments, 8 bytes
+// each; a null address introduces a byte count and raw bytes, padded to 8.
+void log_put(std::vector<uint8_t>& bin, const void* p, size_t n) {
+    const uint8_t* q = (const uint8_t*)p;
+    bin.insert(bin.end(), q, q + n);
+}
+void log_fmt(std::vector<uint8_t>& bin, const char* fmt, ...) {
+    log_put(bin, &fmt, sizeof fmt);
+    va_list ap;
+    va_start(ap, fmt);
+    for (const char* c = fmt; *c; ++c) {
+        if (*c != '%') continue;
+        ++c;
+        if (*c == 'a') { const double v = va_arg(ap, double); log_put(bin, &v, 8); }
+        else if (*c == 'd') { const long long v = va_arg(ap, int); log_put(bin, &v, 8); }
+        else if (*c == 'u') { const long long v = va_arg(ap, unsigned); log_put(bin, &v, 8); }
+        else if (*c == 'z') { ++c; const long long v = (long long)va_arg(ap, size_t); log_put(bin, &v, 8); }
+        else if (*c == 's') { const char* v = va_arg(ap, const char*); log_put(bin, &v, 8); }
+    }
+    va_end(ap);
+}
+void log_raw(std::vector<uint8_t>& bin, const void* data, size_t n) {
+    const char* none = nullptr;
+    const unsigned long long len = n;
+    log_put(bin, &none, sizeof none);
+    log_put(bin, &len, 8);
+    log_put(bin, data, n);
+    bin.resize((bin.size() + 7u) & ~(size_t)7u);
+}
+std::string log_text(const std::vector<uint8_t>& bin) {
+    std::string out;
+    size_t at = 0;
+    char buf[64];
+    while (at + 8 <= bin.size()) {
+        const char* fmt;
+        memcpy(&fmt, bin.data() + at, 8); at += 8;
+        if (!fmt) {
+            unsigned long long len;
+            memcpy(&len, bin.data() + at, 8); at += 8;
+            out.append((const char*)bin.data() + at, (size_t)len);
+            at += ((size_t)len + 7u) & ~(size_t)7u;
+            continue;
+        }
+        for (const char* c = fmt; *c; ++c) {
+            if (*c != '%') { out.push_back(*c); continue; }
+            ++c;
+            if (*c == 'a') { double v; memcpy(&v, bin.data() + at, 8); at += 8; out.append(buf, (size_t)snprintf(buf, sizeof buf, "%a", v)); }
+            else if (*c == 'd') { long long v; memcpy(&v, bin.data() + at, 8); at += 8; out.append(buf, (size_t)snprintf(buf, sizeof buf, "%lld", v)); }
+            else if (*c == 'u') { long long v; memcpy(&v, bin.data() + at, 8); at += 8; out.append(buf, (size_t)snprintf(buf, sizeof buf, "%llu", (unsigned long long)v)); }
+            else if (*c == 'z') { ++c; long long v; memcpy(&v, bin.data() + at, 8); at += 8; out.append(buf, (size_t)snprintf(buf, sizeof buf, "%llu", (unsigned long long)v)); }
+            else if (*c == 's') { const char* v; memcpy(&v, bin.data() + at, 8); at += 8; out.append(v); }
+        }
+    }
+    return out;
 }
 
 // f32 bounds that contain the f64 value: equal to it when it is representable, else the next f32 outward.
@@ -629,11 +688,12 @@ uint32_t rt_builder::emit_replay(Flat& f, const ObjRec& o, int node, int parent,
 }
 
 namespace {
+struct BlobOut { uint8_t* data = nullptr; size_t size = 0; }; // data == nullptr: sections are only laid out
 template <class T>
-void put_section(std::vector<uint8_t>& blob, RtSection& sec, const std::vector<T>& v) {
-    size_t off = (blob.size() + 255u) & ~(size_t)255u;
-    blob.resize(off + v.size() * sizeof(T));
-    if (!v.empty()) memcpy(blob.data() + off, v.data(), v.size() * sizeof(T));
+void put_section(BlobOut& blob, RtSection& sec, const std::vector<T>& v) {
+    const size_t off = (blob.size + 255u) & ~(size_t)255u;
+    if (blob.data && !v.empty()) memcpy(blob.data + off, v.data(), v.size() * sizeof(T));
+    blob.size = off + v.size() * sizeof(T);
     sec.offset = off;
     sec.count = v.size();
 }
@@ -643,6 +703,11 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     if (!blob_out || !nbytes) return fail(RT_ERR_INVALID, "null output");
     if (!valid_obj(world)) return fail(RT_ERR_INVALID, "world handle %d is not a hittable", world);
     Flat f;
+    const bool timing = getenv("RT_DEBUG") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (timing) fprintf(stderr, "rt compile: %s at %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+    };
     valid_lo = -kInf; valid_hi = kInf;
     // world.hit (hittable_list.rs:40-53) returns the closest hit over the world's entries, and that does not depend on
     // the order the entries are tested in or on which of them are skipped because the ray misses their bounds (only
@@ -793,8 +858,9 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         std::vector<char> in_tree(items.size(), 0);
         {
             std::vector<size_t> order;
-            for (size_t i = 0; i < items.size(); ++i) if (items[i].bounded) order.push_back(i);
-            std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return half_area(items[a].box) < half_area(items[b].box); });
+            std::vector<double> area(items.size(), 0.0);
+            for (size_t i = 0; i < items.size(); ++i) if (items[i].bounded) { order.push_back(i); area[i] = half_area(items[i].box); }
+            std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return area[a] < area[b]; });
             AABB acc = kEmptyBox;
             for (size_t k = 0; k < order.size(); ++k) { // ascending: acc = union of everything smaller
                 const Item& it = items[order[k]];
@@ -941,6 +1007,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         shutter.lo = -kInf; shutter.hi = kInf;
     }
     if (flat_ref == RT_REF_NONE && tree_ref == RT_REF_NONE) return fail(RT_ERR_UNSUPPORTED, "empty scene");
+    lap("world arranged");
     // Node numbering: breadth-first from the world's root for the first kBreadthFirst records - the traversal kernel keeps
     // a prefix of the node array in LDS, and these are the records nearest the root, which every ray visits - then
     // depth-first (a node followed by its child-0 subtree), which keeps a deep descent within few cache lines.
@@ -1006,6 +1073,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         remap(tree_ref);
         remap(dt_root);
     }
+    lap("nodes numbered");
     const size_t biggest = std::max({f.nodes.size(), f.spheres.size(), f.mspheres.size(), f.rects.size(), f.boxes.size(), f.media.size(),
                                      f.insts.size(), f.list_entries.size()});
     if (biggest > (size_t)RT_REF_INDEX_MASK) return fail(RT_ERR_UNSUPPORTED, "scene too large: %zu records of one kind, limit %u", biggest, RT_REF_INDEX_MASK);
@@ -1054,25 +1122,35 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         dtex.push_back(d);
     }
 
-    std::vector<uint8_t> blob(sizeof(RtBlobHeader));
+    lap("tables made");
+    // laid out first, then written straight into the allocation the caller gets (the blob of a million spheres is 230 MB)
     RtBlobHeader hd;
     memset(&hd, 0, sizeof hd);
-    put_section(blob, hd.nodes, f.nodes);
-    put_section(blob, hd.spheres, f.spheres); put_section(blob, hd.sphere_meta, f.sphere_meta);
-    put_section(blob, hd.mspheres, f.mspheres); put_section(blob, hd.msphere_meta, f.msphere_meta);
-    put_section(blob, hd.rects, f.rects); put_section(blob, hd.rect_meta, f.rect_meta);
-    put_section(blob, hd.boxes, f.boxes); put_section(blob, hd.box_meta, f.box_meta);
-    put_section(blob, hd.media, f.media);
-    put_section(blob, hd.insts, f.insts);
-    put_section(blob, hd.list_entries, f.list_entries);
-    put_section(blob, hd.materials, dmats);
-    put_section(blob, hd.textures, dtex);
-    put_section(blob, hd.perlin_vec, pvec);
-    put_section(blob, hd.perlin_perm, pperm);
-    put_section(blob, hd.texels, texels);
-    blob.resize((blob.size() + 255u) & ~(size_t)255u);
+    auto put_all = [&](BlobOut& blob) {
+        blob.size = sizeof(RtBlobHeader);
+        put_section(blob, hd.nodes, f.nodes);
+        put_section(blob, hd.spheres, f.spheres); put_section(blob, hd.sphere_meta, f.sphere_meta);
+        put_section(blob, hd.mspheres, f.mspheres); put_section(blob, hd.msphere_meta, f.msphere_meta);
+        put_section(blob, hd.rects, f.rects); put_section(blob, hd.rect_meta, f.rect_meta);
+        put_section(blob, hd.boxes, f.boxes); put_section(blob, hd.box_meta, f.box_meta);
+        put_section(blob, hd.media, f.media);
+        put_section(blob, hd.insts, f.insts);
+        put_section(blob, hd.list_entries, f.list_entries);
+        put_section(blob, hd.materials, dmats);
+        put_section(blob, hd.textures, dtex);
+        put_section(blob, hd.perlin_vec, pvec);
+        put_section(blob, hd.perlin_perm, pperm);
+        put_section(blob, hd.texels, texels);
+        blob.size = (blob.size + 255u) & ~(size_t)255u;
+    };
+    BlobOut blob;
+    put_all(blob);
+    const size_t total = blob.size;
+    blob.data = (uint8_t*)calloc(total, 1); // gaps between sections are zero
+    if (!blob.data) return fail(RT_ERR_OOM, "out of memory");
+    put_all(blob);
     hd.magic = RT_BLOB_MAGIC; hd.version = RT_BLOB_VERSION;
-    hd.total_bytes = blob.size();
+    hd.total_bytes = total;
     hd.world_flat_any_time = flat_any_ref;
     hd.shutter0 = shutter.lo; hd.shutter1 = shutter.hi;
     hd.valid0 = valid_lo; hd.valid1 = valid_hi;
@@ -1092,12 +1170,10 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
             for (int a = 0; a < 3; ++a)
                 if (std::isfinite(b[a])) hd.node_extent = std::max(hd.node_extent, (double)std::fabs(b[a]));
     }
-    memcpy(blob.data(), &hd, sizeof hd);
-    void* out = malloc(blob.size());
-    if (!out) return fail(RT_ERR_OOM, "out of memory");
-    memcpy(out, blob.data(), blob.size());
-    *blob_out = out;
-    *nbytes = blob.size();
+    memcpy(blob.data, &hd, sizeof hd);
+    *blob_out = blob.data;
+    *nbytes = total;
+    lap("blob written");
     return RT_OK;
 }
 
@@ -1108,7 +1184,7 @@ rt_builder* rt_builder_new(uint64_t seed) {
     rt_builder* b = new (std::nothrow) rt_builder();
     if (!b) return nullptr;
     b->rng.seed = seed; b->rng.stream = 1;
-    b->log = "rtdesc 1\n";
+    log_fmt(b->log, "rtdesc 1\n");
     return b;
 }
 void rt_builder_free(rt_builder* b) { delete b; }
@@ -1116,7 +1192,7 @@ const char* rt_builder_last_error(const rt_builder* b) { return b ? b->error.c_s
 int rt_builder_set_flags(rt_builder* b, uint32_t flags) {
     if (!b) return RT_ERR_INVALID;
     b->flags = flags;
-    append_fmt(b->log, "flags %u\n", flags);
+    log_fmt(b->log, "flags %u\n", flags);
     return RT_OK;
 }
 void rt_free(void* p) { free(p); }
@@ -1126,7 +1202,7 @@ int rt_tex_solid(rt_builder* b, double r, double g, double bl) {
     TexRec t; t.type = RT_TEX_SOLID; t.p[0] = r; t.p[1] = g; t.p[2] = bl;
     b->texs.push_back(t);
     int id = (int)b->texs.size() - 1;
-    append_fmt(b->log, "tex_solid %d %a %a %a\n", id, r, g, bl);
+    log_fmt(b->log, "tex_solid %d %a %a %a\n", id, r, g, bl);
     return id;
 }
 int rt_tex_checker(rt_builder* b, int even_tex, int odd_tex) {
@@ -1135,7 +1211,7 @@ int rt_tex_checker(rt_builder* b, int even_tex, int odd_tex) {
     TexRec t; t.type = RT_TEX_CHECKER; t.a = even_tex; t.b = odd_tex;
     b->texs.push_back(t);
     int id = (int)b->texs.size() - 1;
-    append_fmt(b->log, "tex_checker %d %d %d\n", id, even_tex, odd_tex);
+    log_fmt(b->log, "tex_checker %d %d %d\n", id, even_tex, odd_tex);
     return id;
 }
 int rt_tex_noise(rt_builder* b, double scale) {
@@ -1157,10 +1233,10 @@ int rt_tex_noise(rt_builder* b, double scale) {
     }
     b->texs.push_back(t);
     int id = (int)b->texs.size() - 1;
-    append_fmt(b->log, "tex_noise %d %a", id, scale);
-    for (double v : b->texs.back().perlin_vec) append_fmt(b->log, " %a", v);
-    for (int32_t v : b->texs.back().perlin_perm) append_fmt(b->log, " %d", v);
-    b->log += "\n";
+    log_fmt(b->log, "tex_noise %d %a", id, scale);
+    for (double v : b->texs.back().perlin_vec) log_fmt(b->log, " %a", v);
+    for (int32_t v : b->texs.back().perlin_perm) log_fmt(b->log, " %d", v);
+    log_fmt(b->log, "\n");
     return id;
 }
 int rt_tex_image(rt_builder* b, const uint8_t* rgb8, uint32_t width, uint32_t height) {
@@ -1170,9 +1246,9 @@ int rt_tex_image(rt_builder* b, const uint8_t* rgb8, uint32_t width, uint32_t he
     t.texels.assign(rgb8, rgb8 + (size_t)width * height * 3);
     b->texs.push_back(t);
     int id = (int)b->texs.size() - 1;
-    append_fmt(b->log, "tex_image %d %u %u %zu\n", id, width, height, b->texs.back().texels.size());
-    b->log.append((const char*)rgb8, (size_t)width * height * 3);
-    b->log += "\n";
+    log_fmt(b->log, "tex_image %d %u %u %zu\n", id, width, height, b->texs.back().texels.size());
+    log_raw(b->log, rgb8, (size_t)width * height * 3);
+    log_fmt(b->log, "\n");
     return id;
 }
 
@@ -1185,7 +1261,7 @@ int rt_mat_lambertian(rt_builder* b, int tex) {
     if (!b) return RT_ERR_INVALID;
     if (!b->valid_tex(tex)) return b->fail(RT_ERR_INVALID, "lambertian: bad texture handle %d", tex);
     int id = add_mat(b, RT_MAT_LAMBERTIAN, tex, 0, 0, 0, 0);
-    append_fmt(b->log, "mat_lambertian %d %d\n", id, tex);
+    log_fmt(b->log, "mat_lambertian %d %d\n", id, tex);
     return id;
 }
 int rt_mat_metal(rt_builder* b, double r, double g, double bl, double fuzz) {
@@ -1193,27 +1269,27 @@ int rt_mat_metal(rt_builder* b, double r, double g, double bl, double fuzz) {
     double f1 = fuzz;
     if (f1 > 1.0) f1 = 1.0; // material.rs:69-72
     int id = add_mat(b, RT_MAT_METAL, -1, r, g, bl, f1);
-    append_fmt(b->log, "mat_metal %d %a %a %a %a\n", id, r, g, bl, fuzz);
+    log_fmt(b->log, "mat_metal %d %a %a %a %a\n", id, r, g, bl, fuzz);
     return id;
 }
 int rt_mat_dielectric(rt_builder* b, double ir) {
     if (!b) return RT_ERR_INVALID;
     int id = add_mat(b, RT_MAT_DIELECTRIC, -1, ir, 0, 0, 0);
-    append_fmt(b->log, "mat_dielectric %d %a\n", id, ir);
+    log_fmt(b->log, "mat_dielectric %d %a\n", id, ir);
     return id;
 }
 int rt_mat_diffuse_light(rt_builder* b, int tex, double k) {
     if (!b) return RT_ERR_INVALID;
     if (!b->valid_tex(tex)) return b->fail(RT_ERR_INVALID, "diffuse_light: bad texture handle %d", tex);
     int id = add_mat(b, RT_MAT_DIFFUSE_LIGHT, tex, k, 0, 0, 0);
-    append_fmt(b->log, "mat_diffuse_light %d %d %a\n", id, tex, k);
+    log_fmt(b->log, "mat_diffuse_light %d %d %a\n", id, tex, k);
     return id;
 }
 int rt_mat_isotropic(rt_builder* b, int tex) {
     if (!b) return RT_ERR_INVALID;
     if (!b->valid_tex(tex)) return b->fail(RT_ERR_INVALID, "isotropic: bad texture handle %d", tex);
     int id = add_mat(b, RT_MAT_ISOTROPIC, tex, 0, 0, 0, 0);
-    append_fmt(b->log, "mat_isotropic %d %d\n", id, tex);
+    log_fmt(b->log, "mat_isotropic %d %d\n", id, tex);
     return id;
 }
 
@@ -1222,7 +1298,7 @@ int rt_sphere(rt_builder* b, const double c[3], double radius, int mat) {
     if (!c || !b->valid_mat(mat)) return b->fail(RT_ERR_INVALID, "sphere: bad argument");
     ObjRec o; o.kind = OBJ_SPHERE; o.mat = mat; o.d[0] = c[0]; o.d[1] = c[1]; o.d[2] = c[2]; o.d[3] = radius;
     int id = b->add_obj(o);
-    append_fmt(b->log, "sphere %d %a %a %a %a %d\n", id, c[0], c[1], c[2], radius, mat);
+    log_fmt(b->log, "sphere %d %a %a %a %a %d\n", id, c[0], c[1], c[2], radius, mat);
     return id;
 }
 int rt_moving_sphere(rt_builder* b, const double c0[3], const double c1[3], double time0, double time1, double radius,
@@ -1236,7 +1312,7 @@ int rt_moving_sphere(rt_builder* b, const double c0[3], const double c1[3], doub
     for (int i = 0; i < 3; ++i) { o.d[i] = c0[i]; o.d[3 + i] = c1[i]; }
     o.d[6] = time0; o.d[7] = time1; o.d[8] = radius;
     int id = b->add_obj(o);
-    append_fmt(b->log, "moving_sphere %d %a %a %a %a %a %a %a %a %a %d\n", id, c0[0], c0[1], c0[2], c1[0], c1[1], c1[2],
+    log_fmt(b->log, "moving_sphere %d %a %a %a %a %a %a %a %a %a %d\n", id, c0[0], c0[1], c0[2], c1[0], c1[1], c1[2],
                time0, time1, radius, mat);
     return id;
 }
@@ -1246,7 +1322,7 @@ static int add_rect(rt_builder* b, ObjKind kind, const char* name, double a0, do
     if (!b->valid_mat(mat)) return b->fail(RT_ERR_INVALID, "%s: bad material handle %d", name, mat);
     ObjRec o; o.kind = kind; o.mat = mat; o.d[0] = a0; o.d[1] = a1; o.d[2] = b0; o.d[3] = b1; o.d[4] = k;
     int id = b->add_obj(o);
-    append_fmt(b->log, "%s %d %a %a %a %a %a %d\n", name, id, a0, a1, b0, b1, k, mat);
+    log_fmt(b->log, "%s %d %a %a %a %a %a %d\n", name, id, a0, a1, b0, b1, k, mat);
     return id;
 }
 int rt_xy_rect(rt_builder* b, double x0, double x1, double y0, double y1, double k, int mat) {
@@ -1264,7 +1340,7 @@ int rt_box(rt_builder* b, const double p0[3], const double p1[3], int mat) {
     ObjRec o; o.kind = OBJ_BOX; o.mat = mat;
     for (int i = 0; i < 3; ++i) { o.d[i] = p0[i]; o.d[3 + i] = p1[i]; }
     int id = b->add_obj(o);
-    append_fmt(b->log, "box %d %a %a %a %a %a %a %d\n", id, p0[0], p0[1], p0[2], p1[0], p1[1], p1[2], mat);
+    log_fmt(b->log, "box %d %a %a %a %a %a %a %d\n", id, p0[0], p0[1], p0[2], p1[0], p1[1], p1[2], mat);
     return id;
 }
 int rt_translate(rt_builder* b, int child, const double off[3]) {
@@ -1273,7 +1349,7 @@ int rt_translate(rt_builder* b, int child, const double off[3]) {
     ObjRec o; o.kind = OBJ_TRANSLATE; o.child = child; o.d[0] = off[0]; o.d[1] = off[1]; o.d[2] = off[2];
     o.exact_bounds = b->objs[child].exact_bounds;
     int id = b->add_obj(o);
-    append_fmt(b->log, "translate %d %d %a %a %a\n", id, child, off[0], off[1], off[2]);
+    log_fmt(b->log, "translate %d %d %a %a %a\n", id, child, off[0], off[1], off[2]);
     return id;
 }
 int rt_rotate_y(rt_builder* b, int child, double angle) {
@@ -1303,7 +1379,7 @@ int rt_rotate_y(rt_builder* b, int child, double angle) {
         for (int c = 0; c < 3; ++c) { o.box.lo[c] = mn[c]; o.box.hi[c] = mx[c]; }
     }
     int id = b->add_obj(o);
-    append_fmt(b->log, "rotate_y %d %d %a\n", id, child, angle);
+    log_fmt(b->log, "rotate_y %d %d %a\n", id, child, angle);
     return id;
 }
 int rt_constant_medium(rt_builder* b, int boundary, double density, double r, double g, double bl) {
@@ -1317,7 +1393,7 @@ int rt_constant_medium(rt_builder* b, int boundary, double density, double r, do
     o.exact_bounds = b->objs[boundary].exact_bounds;
     o.medium_index = b->n_media++;
     int id = b->add_obj(o);
-    append_fmt(b->log, "constant_medium %d %d %a %a %a %a %d %d\n", id, boundary, density, r, g, bl, mat, (int)b->texs.size() - 1);
+    log_fmt(b->log, "constant_medium %d %d %a %a %a %a %d %d\n", id, boundary, density, r, g, bl, mat, (int)b->texs.size() - 1);
     return id;
 }
 int rt_list_new(rt_builder* b) {
@@ -1325,7 +1401,7 @@ int rt_list_new(rt_builder* b) {
     ObjRec o; o.kind = OBJ_LIST;
     o.exact_bounds = false;
     int id = b->add_obj(o);
-    append_fmt(b->log, "list %d\n", id);
+    log_fmt(b->log, "list %d\n", id);
     return id;
 }
 int rt_list_add(rt_builder* b, int list, int child) {
@@ -1333,7 +1409,7 @@ int rt_list_add(rt_builder* b, int list, int child) {
     if (!b->valid_obj(list) || b->objs[list].kind != OBJ_LIST || !b->valid_obj(child) || child == list)
         return b->fail(RT_ERR_INVALID, "list_add: bad handle");
     b->objs[list].members.push_back(child);
-    append_fmt(b->log, "list_add %d %d\n", list, child);
+    log_fmt(b->log, "list_add %d %d\n", list, child);
     return RT_OK;
 }
 int rt_bvh(rt_builder* b, int list, double t0, double t1) {
@@ -1377,9 +1453,9 @@ int rt_bvh(rt_builder* b, int list, double t0, double t1) {
     }
     int id = b->add_obj(std::move(o));
     // the axes drawn (bvh.rs:22), in construction order, so that a replay can rebuild the same tree
-    append_fmt(b->log, "bvh %d %d %a %a ", id, list, t0, t1);
-    b->log += b->axis_log;
-    b->log += "\n";
+    log_fmt(b->log, "bvh %d %d %a %a ", id, list, t0, t1);
+    log_raw(b->log, b->axis_log.data(), b->axis_log.size());
+    log_fmt(b->log, "\n");
     return id;
 }
 
@@ -1391,7 +1467,7 @@ int rt_builder_compile(rt_builder* b, int world, void** blob, size_t* nbytes) {
 int rt_builder_describe(rt_builder* b, int world, char** text, size_t* nbytes) {
     if (!b) return RT_ERR_INVALID;
     if (!text || !nbytes || !b->valid_obj(world)) return b->fail(RT_ERR_INVALID, "describe: bad argument");
-    std::string s = b->log;
+    std::string s = log_text(b->log);
     append_fmt(s, "world %d\n", world);
     char* out = (char*)malloc(s.size() + 1);
     if (!out) return b->fail(RT_ERR_OOM, "out of memory");

@@ -77,7 +77,7 @@ struct rt_builder {
     std::vector<MatRec> mats;
     std::vector<TexRec> texs;
     std::map<std::string, Image> images;
-    std::string log;
+    std::vector<uint8_t> log; // constructor log as compact records (rt_builder.cpp: log_fmt / log_text)
     std::string axis_log; // split axes of the BVH being built, one digit per BvhNode::new call
     std::string error;
     double valid_lo = -std::numeric_limits<double>::infinity(), valid_hi = std::numeric_limits<double>::infinity(); // set by compile()
