@@ -119,3 +119,46 @@ def test_random_scene_graphs_with_device_built_trees(gpu_ctx, seed):
         rep = util.first_hit_report(gpu_ctx.trace_first_hit(scene, rays, xi), osc.trace_first_hit(rays, xi))
         assert rep["prim_match"] >= 0.9995 and rep["t_rel_max"] <= 1e-5 and rep["t_bit_equal"] >= 0.95, (seed, flags, rep)
         scene.close()
+
+
+def _chain_scene(extra_at_origin):
+    """Centres at 1000 * 2^-k along each axis: every Morton bit separates one of them from the rest, so the hierarchy
+    over full-resolution codes is a chain some sixty nodes tall."""
+    b = api.Builder(seed=util.SCENE_SEED, flags=api.FLAG_DEVICE_TREE)
+    mat = b.lambertian_color(0.5, 0.5, 0.5)
+    centres = [(0.0, 0.0, 0.0)]
+    for k in range(1, 22):
+        x = 1000.0 * 2.0 ** -k
+        centres += [(x, 0.0, 0.0), (0.0, x, 0.0), (0.0, 0.0, x)]
+    centres += [(1e-5 * (i % 7), 1e-5 * (i % 11), 1e-5 * (i % 13)) for i in range(extra_at_origin)]
+    world = b.list([b.sphere(c, 1e-4 * (1 + i % 5), mat) for i, c in enumerate(centres)])
+    return b.compile(world), b.describe(world), np.array(centres)
+
+
+def test_a_tree_too_tall_for_the_stack_is_rebuilt_from_coarser_codes(gpu_ctx):
+    blob, desc, centres = _chain_scene(0)
+    scene = gpu_ctx.upload(blob)
+    st = gpu_ctx.build_tree(scene)
+    assert st.key_bits == 30 and st.height <= 38 and st.stack_need <= 39, (st.key_bits, st.height)
+    osc = ck.OracleScene(desc)
+    rng = np.random.default_rng(9)
+    o = rng.uniform(-50.0, 1100.0, (4000, 3))
+    rays = util.rays_from(o, centres[rng.integers(0, len(centres), 4000)] + rng.normal(0.0, 1e-4, (4000, 3)) - o)
+    rep = util.first_hit_report(gpu_ctx.trace_first_hit(scene, rays), osc.trace_first_hit(rays))
+    assert rep["prim_match"] == 1.0 and rep["both_hit"].sum() > 500, rep
+    scene.close()
+
+
+def test_a_tree_too_tall_even_then_leaves_the_standin_in_place(gpu_ctx):
+    blob, desc, centres = _chain_scene(3000)     # thirty chain levels above a dozen levels of coincident centres
+    scene = gpu_ctx.upload(blob)
+    with pytest.raises(api.RtError) as e:
+        gpu_ctx.build_tree(scene)
+    assert e.value.code == -2 and "tall" in str(e.value)
+    osc = ck.OracleScene(desc)
+    rng = np.random.default_rng(10)
+    o = rng.uniform(-50.0, 1100.0, (4000, 3))
+    rays = util.rays_from(o, centres[rng.integers(0, len(centres), 4000)] + rng.normal(0.0, 1e-4, (4000, 3)) - o)
+    rep = util.first_hit_report(gpu_ctx.trace_first_hit(scene, rays), osc.trace_first_hit(rays))
+    assert rep["prim_match"] == 1.0 and rep["both_hit"].sum() > 500, rep
+    scene.close()
