@@ -177,7 +177,7 @@ void rt_scene_free(rt_context*, rt_scene*);
 
 /* BvhNode::new (bvh.rs:15-66) for the world's tree, on the device: for a scene compiled with builder flag bit 3, arranges
  * the leaves of the stand-in tree by a linear BVH build (Morton codes of the leaf centroids, radix sort, hierarchy and
- * boxes in parallel) and writes the nodes over the stand-in's. Closest hits are those of any other tree over the same
+ * boxes in parallel, two passes of tree rotations) and writes the nodes over the stand-in's. Closest hits are those of any other tree over the same
  * objects. RT_ERR_INVALID for a scene compiled without the flag or built already; RT_ERR_UNSUPPORTED when the tree would be taller than
  * the traversal stack (the stand-in then stays, and the scene stays usable). No render may be in flight on the scene. */
 typedef struct {

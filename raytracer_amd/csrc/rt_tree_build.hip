@@ -4,8 +4,8 @@
 // replaces that with a surface-area-heuristic build, which for a million objects takes seconds of one host core. Here the
 // same leaves are arranged by a linear BVH build instead: 63-bit Morton codes of the leaf centroids, one radix sort, the
 // hierarchy of T. Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees" (HPG 2012) -
-// internal node i of the sorted sequence finds its own range and split by binary searches over common prefixes - and one
-// bottom-up pass that unites the boxes. What a BVH returns (the closest hit) does not depend on how its leaves are
+// internal node i of the sorted sequence finds its own range and split by binary searches over common prefixes - and
+// bottom-up passes that unite the boxes and rotate subtrees where that shrinks them. What a BVH returns (the closest hit) does not depend on how its leaves are
 // grouped as long as every box bounds what is below it, so the result is the tree the traversal kernels already walk:
 // 64-byte nodes holding both children's boxes, nearest child first.
 //
@@ -170,54 +170,129 @@ __global__ void __launch_bounds__(TB_BLOCK) k_tb_hierarchy(const uint64_t* __res
 
 __device__ inline uint32_t tb_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Box and height of child `c` of a node whose children are both complete.
-__device__ inline void tb_child(uint32_t c, const uint32_t* __restrict__ vals, const TbBox* __restrict__ leaf_box, const RtNode* tmp,
-                                TbBox& box, uint32_t& height) {
+// Child `c` of a node whose children are both complete: its box and height and, for an internal node, what it holds.
+struct TbKid {
+    TbBox box;
+    uint32_t height;
+    bool internal;
+    TbBox b[2];      // boxes of its own two children
+    uint32_t c[2];   // their ids
+    uint32_t h[2];   // and the heights of their subtrees
+};
+__device__ inline TbBox tb_union(const TbBox& x, const TbBox& y) {
+    TbBox o;
+    for (int a = 0; a < 3; ++a) { o.lo[a] = fminf(x.lo[a], y.lo[a]); o.hi[a] = fmaxf(x.hi[a], y.hi[a]); }
+    return o;
+}
+__device__ inline float tb_area(const TbBox& x) {
+    const float dx = x.hi[0] - x.lo[0], dy = x.hi[1] - x.lo[1], dz = x.hi[2] - x.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+__device__ inline uint32_t tb_max(uint32_t x, uint32_t y) { return x > y ? x : y; }
+__device__ inline TbKid tb_child(uint32_t c, const uint32_t* __restrict__ vals, const TbBox* __restrict__ leaf_box, const RtNode* tmp) {
+    TbKid k;
     if (c & TB_LEAF) {
-        box = leaf_box[vals[c & ~TB_LEAF]];
-        height = 0u;
-        return;
+        k.box = leaf_box[vals[c & ~TB_LEAF]];
+        k.height = 0u;
+        k.internal = false;
+        k.b[0] = k.b[1] = k.box; k.c[0] = k.c[1] = c; k.h[0] = k.h[1] = 0u;
+        return k;
     }
     const uint32_t* w = (const uint32_t*)(tmp + c); // written by another workgroup: read past the vector cache
     float v[12];
-    for (int k = 0; k < 12; ++k) v[k] = __uint_as_float(tb_ld(w + k));
-    for (int a = 0; a < 3; ++a) { box.lo[a] = fminf(v[a], v[6 + a]); box.hi[a] = fmaxf(v[3 + a], v[9 + a]); }
-    height = tb_ld(w + 15);
+    for (int i = 0; i < 12; ++i) v[i] = __uint_as_float(tb_ld(w + i));
+    for (int a = 0; a < 3; ++a) { k.b[0].lo[a] = v[a]; k.b[0].hi[a] = v[3 + a]; k.b[1].lo[a] = v[6 + a]; k.b[1].hi[a] = v[9 + a]; }
+    k.c[0] = tb_ld(w + 12); k.c[1] = tb_ld(w + 13);
+    k.h[0] = tb_ld(w + 14); k.h[1] = tb_ld(w + 15);
+    k.box = tb_union(k.b[0], k.b[1]);
+    k.height = 1u + tb_max(k.h[0], k.h[1]);
+    k.internal = true;
+    return k;
+}
+__device__ inline void tb_write(RtNode* dst, const TbBox& b0, const TbBox& b1, uint32_t c0, uint32_t c1, uint32_t h0, uint32_t h1) {
+    RtNode nd;
+    for (int a = 0; a < 3; ++a) { nd.lo0[a] = b0.lo[a]; nd.hi0[a] = b0.hi[a]; nd.lo1[a] = b1.lo[a]; nd.hi1[a] = b1.hi[a]; }
+    nd.c0 = c0; nd.c1 = c1;
+    nd.pad[0] = h0; nd.pad[1] = h1; // while the tree is being built: heights of the two subtrees
+    *dst = nd;
 }
 
 // One lane per leaf climbs towards the root; at every node the first of the two arrivals stops and the second, which
-// knows that both children are complete, writes the node (children still as Karras ids, the height in pad[1]).
+// knows that both children are complete, writes the node (children still as Karras ids, subtree heights in pad[]).
+//
+// Before it does, it may improve on what the Morton order dictated: a node with children L = {a, b} and R may hand
+// one grandchild up and take R in its place (L' = {R, b} beside a, or L' = {a, R} beside b; the same with the sides
+// exchanged) when that makes the rebuilt child's box smaller in surface area - the tree rotations of
+// A. Kensler, "Tree Rotations for Improving Bounding Volume Hierarchies" (RT 2008), applied once, bottom-up. Everything
+// such a step touches lies below the node, and below a node only the lane that writes it is still at work.
 __global__ void __launch_bounds__(TB_BLOCK) k_tb_refit(uint32_t n, const uint32_t* __restrict__ vals, const TbBox* __restrict__ leaf_box,
                                                        const uint32_t* __restrict__ kids, const uint32_t* __restrict__ iparent,
-                                                       const uint32_t* __restrict__ lparent, uint32_t* visit, RtNode* tmp, uint32_t* status) {
+                                                       const uint32_t* __restrict__ lparent, uint32_t* visit, RtNode* tmp, uint32_t rotate,
+                                                       uint32_t first_pass, uint32_t* status) {
     const uint32_t p = blockIdx.x * TB_BLOCK + threadIdx.x;
     if (p >= n) return;
     uint32_t cur = lparent[p];
-    for (int step = 0; step < 128; ++step) { // a Karras tree over 64 + 32 key bits is at most 96 nodes tall
+    for (int step = 0; step < 160; ++step) { // a Karras tree over 64 + 32 key bits is at most 96 nodes tall, a rotation adds at most one level
         __threadfence();
         const uint32_t earlier = atomicAdd(&visit[cur], 1u);
         if (earlier == 0u) return;
         __threadfence();
-        const uint32_t l = kids[2u * cur], r = kids[2u * cur + 1u];
-        TbBox bl, br;
-        uint32_t hl, hr;
-        tb_child(l, vals, leaf_box, tmp, bl, hl);
-        tb_child(r, vals, leaf_box, tmp, br, hr);
-        RtNode nd;
-        for (int a = 0; a < 3; ++a) { nd.lo0[a] = bl.lo[a]; nd.hi0[a] = bl.hi[a]; nd.lo1[a] = br.lo[a]; nd.hi1[a] = br.hi[a]; }
-        nd.c0 = l; nd.c1 = r;
-        nd.pad[0] = 0u;
-        nd.pad[1] = 1u + (hl > hr ? hl : hr);
-        tmp[cur] = nd;
-        if (cur == 0u) { status[ST_HEIGHT] = nd.pad[1]; return; }
+        // the node's children: from the hierarchy on the first pass, from the node itself (as the pass before left it) later
+        const uint32_t id[2] = {first_pass ? kids[2u * cur] : tmp[cur].c0, first_pass ? kids[2u * cur + 1u] : tmp[cur].c1};
+        TbKid k[2] = {tb_child(id[0], vals, leaf_box, tmp), tb_child(id[1], vals, leaf_box, tmp)};
+        // choice = 2 * side + which: the child on `side` keeps its grandchild `1 - which`, hands `which` up, takes the other child in
+        // (the surface-area cost of a tree is the sum of its nodes' areas: a rotation changes one term of it, the rebuilt child's)
+        float best = 0.0f;
+        int choice = -1;
+        if (rotate)
+            for (int side = 0; side < 2; ++side)
+                if (k[side].internal) {
+                    const float before = tb_area(k[side].box);
+                    for (int which = 0; which < 2; ++which) {
+                        const float gain = before - tb_area(tb_union(k[1 - side].box, k[side].b[1 - which]));
+                        if (gain > best && gain > 1e-3f * before) { best = gain; choice = 2 * side + which; }
+                    }
+                }
+        if (choice < 0) {
+            tb_write(tmp + cur, k[0].box, k[1].box, id[0], id[1], k[0].height, k[1].height);
+        } else {
+            const int side = choice >> 1, which = choice & 1;
+            const TbKid& in = k[side];      // the child that is rebuilt
+            const TbKid& other = k[1 - side]; // the child that moves down into it
+            const TbBox merged = tb_union(other.box, in.b[1 - which]);
+            const uint32_t merged_h = 1u + tb_max(other.height, in.h[1 - which]);
+            // the rebuilt child: the moved-in subtree takes the place of the grandchild that went up
+            if (which == 0) tb_write(tmp + id[side], other.box, in.b[1], id[1 - side], in.c[1], other.height, in.h[1]);
+            else tb_write(tmp + id[side], in.b[0], other.box, in.c[0], id[1 - side], in.h[0], other.height);
+            // this node: the rebuilt child stays on its side, the grandchild takes the other side
+            if (side == 0) tb_write(tmp + cur, merged, in.b[which], id[0], in.c[which], merged_h, in.h[which]);
+            else tb_write(tmp + cur, in.b[which], merged, in.c[which], id[1], in.h[which], merged_h);
+        }
+        if (cur == 0u) {
+            const uint32_t* w = (const uint32_t*)(tmp + cur);
+            status[ST_HEIGHT] = 1u + tb_max(w[14], w[15]);
+            return;
+        }
         cur = iparent[cur];
     }
     atomicOr(&status[ST_ERROR], 4u);
 }
 
+// Parents as the rotations left them, for another climb.
+__global__ void __launch_bounds__(TB_BLOCK) k_tb_parents(uint32_t n_internal, const RtNode* __restrict__ tmp, uint32_t* __restrict__ iparent,
+                                                         uint32_t* __restrict__ lparent) {
+    const uint32_t i = blockIdx.x * TB_BLOCK + threadIdx.x;
+    if (i >= n_internal) return;
+    const uint32_t c[2] = {tmp[i].c0, tmp[i].c1};
+    for (int k = 0; k < 2; ++k) {
+        if (c[k] & TB_LEAF) lparent[c[k] & ~TB_LEAF] = i;
+        else iparent[c[k]] = i;
+    }
+}
+
 // One workgroup: the first `top` nodes in breadth-first order from the root get positions 0..top-1; the nodes that sat
 // at those positions and are not among them take the positions the others left.
-__global__ void __launch_bounds__(1024) k_tb_top(uint32_t n_internal, uint32_t top, const uint32_t* __restrict__ kids, uint32_t* order,
+__global__ void __launch_bounds__(1024) k_tb_top(uint32_t n_internal, uint32_t top, const RtNode* __restrict__ tmp, uint32_t* order,
                                                  uint32_t* clist, uint32_t* newpos, const uint32_t* __restrict__ slot_sorted, uint32_t root,
                                                  uint32_t n_nodes, uint32_t* status) {
     __shared__ uint32_t cnt, ccnt;
@@ -236,7 +311,7 @@ __global__ void __launch_bounds__(1024) k_tb_top(uint32_t n_internal, uint32_t t
     while (b < top && a < b) {
         for (uint32_t idx = a + tid; idx < b; idx += 1024u) {
             const uint32_t node = order[idx];
-            const uint32_t c[2] = {kids[2u * node], kids[2u * node + 1u]};
+            const uint32_t c[2] = {tmp[node].c0, tmp[node].c1};
             for (int k = 0; k < 2; ++k)
                 if (!(c[k] & TB_LEAF)) {
                     const uint32_t pos = atomicAdd(&cnt, 1u);
@@ -294,6 +369,9 @@ int rt_tree_build_device(hipStream_t stream, RtNode* d_nodes, size_t n_nodes, ui
     if (n > TB_MAX_LEAVES || (size_t)n - 1u > n_nodes) { err = "tree build: leaf count out of range"; return RT_ERR_INVALID; }
     const uint32_t ni = n - 1u;
     const uint32_t top = ni < TB_TOP ? ni : TB_TOP;
+    const uint32_t rotate = getenv("RT_TREE_NO_ROTATIONS") ? 0u : 1u; // (for A/B measurements)
+    uint32_t rotation_passes = 2u;
+    if (const char* e = getenv("RT_TREE_ROTATION_PASSES")) rotation_passes = (uint32_t)std::max(1, std::min(8, atoi(e)));
 
     size_t cub_pairs = 0, cub_keys = 0;
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, cub_pairs, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
@@ -374,9 +452,16 @@ int rt_tree_build_device(hipStream_t stream, RtNode* d_nodes, size_t n_nodes, ui
             hipEventRecord(ev[2], stream);
             hipLaunchKernelGGL(k_tb_hierarchy, dim3(grid_i), dim3(TB_BLOCK), 0, stream, (const uint64_t*)keys_sorted, n, kids, iparent, lparent, newpos);
             hipEventRecord(ev[3], stream);
-            hipLaunchKernelGGL(k_tb_refit, dim3(grid_n), dim3(TB_BLOCK), 0, stream, n, (const uint32_t*)vals_sorted, (const TbBox*)leaf_box,
-                               (const uint32_t*)kids, (const uint32_t*)iparent, (const uint32_t*)lparent, visit, tmp, status);
-            hipLaunchKernelGGL(k_tb_top, dim3(1), dim3(1024), 0, stream, ni, top, (const uint32_t*)kids, order, clist, newpos,
+            for (uint32_t pass = 0; pass < (rotate ? rotation_passes : 1u); ++pass) {
+                if (pass > 0u) {
+                    hipLaunchKernelGGL(k_tb_parents, dim3(grid_i), dim3(TB_BLOCK), 0, stream, ni, (const RtNode*)tmp, iparent, lparent);
+                    (void)hipMemsetAsync(visit, 0, (size_t)ni * 4, stream);
+                }
+                hipLaunchKernelGGL(k_tb_refit, dim3(grid_n), dim3(TB_BLOCK), 0, stream, n, (const uint32_t*)vals_sorted, (const TbBox*)leaf_box,
+                                   (const uint32_t*)kids, (const uint32_t*)iparent, (const uint32_t*)lparent, visit, tmp, rotate,
+                                   pass == 0u ? 1u : 0u, status);
+            }
+            hipLaunchKernelGGL(k_tb_top, dim3(1), dim3(1024), 0, stream, ni, top, (const RtNode*)tmp, order, clist, newpos,
                                (const uint32_t*)slot_sorted, root, (uint32_t)n_nodes, status);
             hipEventRecord(ev[4], stream);
             e = hipGetLastError();

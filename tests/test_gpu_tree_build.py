@@ -135,7 +135,8 @@ def _chain_scene(extra_at_origin):
     return b.compile(world), b.describe(world), np.array(centres)
 
 
-def test_a_tree_too_tall_for_the_stack_is_rebuilt_from_coarser_codes(gpu_ctx):
+def test_a_tree_too_tall_for_the_stack_is_rebuilt_from_coarser_codes(gpu_ctx, monkeypatch):
+    monkeypatch.setenv("RT_TREE_NO_ROTATIONS", "1")   # (rotations shorten such a chain; this test is about the fallback)
     blob, desc, centres = _chain_scene(0)
     scene = gpu_ctx.upload(blob)
     st = gpu_ctx.build_tree(scene)
@@ -149,7 +150,8 @@ def test_a_tree_too_tall_for_the_stack_is_rebuilt_from_coarser_codes(gpu_ctx):
     scene.close()
 
 
-def test_a_tree_too_tall_even_then_leaves_the_standin_in_place(gpu_ctx):
+def test_a_tree_too_tall_even_then_leaves_the_standin_in_place(gpu_ctx, monkeypatch):
+    monkeypatch.setenv("RT_TREE_NO_ROTATIONS", "1")
     blob, desc, centres = _chain_scene(3000)     # thirty chain levels above a dozen levels of coincident centres
     scene = gpu_ctx.upload(blob)
     with pytest.raises(api.RtError) as e:
@@ -162,3 +164,22 @@ def test_a_tree_too_tall_even_then_leaves_the_standin_in_place(gpu_ctx):
     rep = util.first_hit_report(gpu_ctx.trace_first_hit(scene, rays), osc.trace_first_hit(rays))
     assert rep["prim_match"] == 1.0 and rep["both_hit"].sum() > 500, rep
     scene.close()
+
+
+def test_the_chain_scenes_with_rotations(gpu_ctx):
+    """The same degenerate scenes with the build as it runs by default: whatever height it ends at, the hits are the oracle's."""
+    for extra in (0, 3000):
+        blob, desc, centres = _chain_scene(extra)
+        scene = gpu_ctx.upload(blob)
+        try:
+            st = gpu_ctx.build_tree(scene)
+            assert st.stack_need <= 39
+        except api.RtError as e:
+            assert e.code == -2
+        osc = ck.OracleScene(desc)
+        rng = np.random.default_rng(11)
+        o = rng.uniform(-50.0, 1100.0, (4000, 3))
+        rays = util.rays_from(o, centres[rng.integers(0, len(centres), 4000)] + rng.normal(0.0, 1e-4, (4000, 3)) - o)
+        rep = util.first_hit_report(gpu_ctx.trace_first_hit(scene, rays), osc.trace_first_hit(rays))
+        assert rep["prim_match"] == 1.0 and rep["both_hit"].sum() > 500, rep
+        scene.close()
