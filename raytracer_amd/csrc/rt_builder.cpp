@@ -473,7 +473,7 @@ struct Kid { int node = -1, obj = -1; AABB box = kEmptyBox; }; // node >= 0: TNo
 struct TNode { Kid kid[2]; };
 struct SahItem { int obj; AABB box; double c[3]; };
 
-const int kSweepMax = 128; // at most this many objects: exact sweep over sorted centroids; more: 32 bins per axis
+const int kSweepMax = 512; // at most this many objects: exact sweep over sorted centroids; more: 32 bins per axis
 const int kBins = 32;
 const int kMaxTreeDepth = 30;
 
