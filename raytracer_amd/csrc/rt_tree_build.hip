@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(TB_BLOCK) k_tb_refit(uint32_t n, const uint32_
     if (p >= n) return;
     uint32_t cur = lparent[p];
     for (int step = 0; step < 160; ++step) { // a Karras tree over 64 + 32 key bits is at most 96 nodes tall, a rotation adds at most one level
-        __threadfence();
+        if (step > 0) __threadfence(); // publish the node written in the step before (a lane that starts at its leaf has written nothing yet)
         const uint32_t earlier = atomicAdd(&visit[cur], 1u);
         if (earlier == 0u) return;
         __threadfence();
