@@ -1,3 +1,4 @@
+"""One line per tools/tree_build_timing.py result file: rays/s on the host-built and the device-built tree, height, climb time."""
 import json, sys
 for f in sys.argv[1:]:
     d = json.loads(open(f).read().strip().split("\n")[-1])
