@@ -272,9 +272,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtCameraDev cam, PassInfo p
             mine[lane * 4u + 1u] = make_double2(r.o.z, r.d.x);
             mine[lane * 4u + 2u] = make_double2(r.d.y, r.d.z);
             mine[lane * 4u + 3u] = make_double2(r.tm, __longlong_as_double((long long)(((unsigned long long)id.pixel << 32) | id.slot)));
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // (lanes read other lanes' writes: keeps the compiler from reordering them)
             double2* out = (double2*)(pb.ray[0] + slot0);
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) out[k * 64u + lane] = mine[k * 64u + lane];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         } else {
             store_ray(pb.ray[0] + slot, r, id);
         }
@@ -578,15 +580,40 @@ __global__ void __launch_bounds__(RT_BLOCK, 5) k_shade_main(DScene sc, PassInfo 
 }
 
 // pixel_color += ray_color(...) in sample order (main.rs:165), continuing from earlier passes.
+// One wave per pixel: the pixel's S sample radiances are 24 S bytes in a row; the wave reads them 64 samples at a time
+// (coalesced), lays them out in LDS, and three lanes - one per colour channel - add them up in sample order, while the
+// next 64 samples are already on their way. (A lane per pixel, each walking its own 24 S bytes, kept 64 cache lines in
+// flight per wave and re-fetched most of them: 2.6 TB/s.)
 __global__ void __launch_bounds__(RT_BLOCK) k_accumulate(PassInfo pi, PathBufs pb, double* sum) {
-    for (uint32_t lp = blockIdx.x * RT_BLOCK + threadIdx.x; lp < pi.n_local; lp += gridDim.x * RT_BLOCK) {
+    __shared__ double stg[RT_BLOCK / 64][192];
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t total = 3u * pi.S; // doubles per pixel
+    const uint32_t n_chunks = (total + 191u) / 192u;
+    for (uint32_t lp = blockIdx.x * (RT_BLOCK / 64u) + wave; lp < pi.n_local; lp += gridDim.x * (RT_BLOCK / 64u)) {
+        const double* rad = pb.rad + (size_t)lp * total;
         const size_t o = (size_t)pi.pixmap[lp] * 3u;
-        double r = sum[o], g = sum[o + 1], b = sum[o + 2];
-        for (uint32_t s = 0; s < pi.S; ++s) {
-            const double* rad = pb.rad + 3u * ((size_t)lp * pi.S + s);
-            r += rad[0]; g += rad[1]; b += rad[2];
+        double acc = lane < 3u ? sum[o + lane] : 0.0;
+        double v[3];
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; ++k) { const uint32_t i = lane + 64u * k; v[k] = i < total ? rad[i] : 0.0; }
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+#pragma unroll
+            for (uint32_t k = 0; k < 3u; ++k) stg[wave][lane + 64u * k] = v[k];
+            // lanes read what other lanes of the wave wrote: without the fences the compiler, which reasons lane by lane,
+            // may move the reads above the writes (it did)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (c + 1u < n_chunks) {
+#pragma unroll
+                for (uint32_t k = 0; k < 3u; ++k) { const uint32_t i = (c + 1u) * 192u + lane + 64u * k; v[k] = i < total ? rad[i] : 0.0; }
+            }
+            const uint32_t here = pi.S - c * 64u < 64u ? pi.S - c * 64u : 64u; // samples in this chunk
+            if (lane < 3u) {
+#pragma unroll 8
+                for (uint32_t smp = 0; smp < here; ++smp) acc += stg[wave][smp * 3u + lane];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
-        sum[o] = r; sum[o + 1] = g; sum[o + 2] = b;
+        if (lane < 3u) sum[o + lane] = acc;
     }
 }
 
@@ -1145,7 +1172,7 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
             launch_shade<RT_BUCKET_ISOTROPIC_TEX>(ctx, &local, pi, pb, qs, it, g_sh, tm);
         }
         a = tm.begin();
-        hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx, n_local, 8)), dim3(RT_BLOCK), 0, ctx->stream, pi, pb, d_rgb_sum);
+        hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx, (size_t)n_local * 64u, 8)), dim3(RT_BLOCK), 0, ctx->stream, pi, pb, d_rgb_sum);
         tm.end(a, 7);
         RT_HIP(hipGetLastError(), "kernel launch");
         RT_HIP(hipMemcpyAsync(host_counters.data(), ctx->counters, n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream),

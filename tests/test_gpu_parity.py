@@ -240,6 +240,11 @@ def test_results_do_not_depend_on_pass_size_tiles_or_rank_count(gpu_ctx):
     assert np.array_equal(ref, again)                                                          # run to run
     by_one = gpu_ctx.render(scene, info.camera, api.params_from_info(info, spp_per_pass=1, **base), 5)
     assert np.array_equal(ref, by_one)                                                         # pass size
+    # the per-pixel sum is taken 64 samples at a time: passes of one chunk, of several, and of a ragged last one
+    small = dict(width=24, height=16, seed=util.RENDER_SEED)
+    want = gpu_ctx.render(scene, info.camera, api.params_from_info(info, spp_per_pass=7, **small), 203)
+    for per_pass in (64, 100, 203):
+        assert np.array_equal(gpu_ctx.render(scene, info.camera, api.params_from_info(info, spp_per_pass=per_pass, **small), 203), want), per_pass
     for world, tile in ((2, 32), (4, 16), (8, 32), (3, 8)):
         total = np.zeros_like(ref)
         for rank in range(world):
