@@ -196,6 +196,16 @@ int rt_scene_build_tree_device(rt_context*, rt_scene*, rt_tree_stats* stats /* n
 int rt_trace_first_hit(rt_context*, const rt_scene*, const rt_ray_d* rays, size_t n, const double* medium_xi,
                        rt_hit* out);
 
+/* rt_trace_first_hit without any allocation. No counterpart in the reference: it is for callers that cannot allocate
+ * device memory while they run - code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * Same arguments and same results, bit for bit; the staging copies of rays, uniforms and hit records and the kernel's
+ * overflow flag live in a fixed 16 MiB work area that the library holds on every GPU it runs on, so the batch is
+ * limited: n * (72 + 96 + 8 * n_media [0 when medium_xi is NULL]) <= 16 MiB - 768 bytes (about 99 000 rays without
+ * uniforms); RT_ERR_INVALID with the limit in rt_last_error beyond that. The work area is shared by every context on
+ * the same GPU: calls that overlap on one GPU race. */
+int rt_trace_first_hit_noalloc(rt_context*, const rt_scene*, const rt_ray_d* rays, size_t n, const double* medium_xi,
+                               rt_hit* out);
+
 /* Camera::get_ray behind the pixel jitter (main.rs:162-164, camera.rs:56-64) for sample `sample` of each
  * pixel: out[(y*width + x)] for the whole image. For tests. */
 int rt_generate_rays(rt_context*, const rt_camera*, const rt_params*, uint32_t sample, rt_ray_d* out);

@@ -200,14 +200,15 @@ class Context:
         self._chk(lib.rt_scene_build_tree_device(self._c, scene._h, C.byref(st)))
         return st
 
-    def trace_first_hit(self, scene, rays, medium_xi=None):
+    def trace_first_hit(self, scene, rays, medium_xi=None, noalloc=False):
+        """noalloc=True: through rt_trace_first_hit_noalloc (fixed work area, limited batch, no device allocation)."""
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
         out = np.zeros(len(rays), dtype=HIT_DTYPE)
         xi = None
         if medium_xi is not None:
             xi = np.ascontiguousarray(medium_xi, dtype=np.float64)
-        self._chk(lib.rt_trace_first_hit(self._c, scene._h, rays.ctypes.data, len(rays), xi.ctypes.data if xi is not None else None,
-                                         out.ctypes.data))
+        fn = lib.rt_trace_first_hit_noalloc if noalloc else lib.rt_trace_first_hit
+        self._chk(fn(self._c, scene._h, rays.ctypes.data, len(rays), xi.ctypes.data if xi is not None else None, out.ctypes.data))
         return out
 
     def generate_rays(self, camera, params, sample):

@@ -673,6 +673,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_camera_rays(RtCameraDev cam, uint3
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------
+// rt_trace_first_hit_noalloc: everything rt_trace_first_hit gets from hipMalloc - the staging copies of the caller's rays,
+// uniforms and hit records, and the word the kernel raises on a stack overflow - lives in this array instead. Every GPU
+// the library runs on holds its own copy, at its own address, until the process ends; in host code the array's name is
+// only a handle for hipGetSymbolAddress, never a device address.
+#define RT_NOALLOC_BYTES (16u << 20)
+#define RT_NOALLOC_HEAD 256u /* [0, 4): the overflow flag; staging starts behind it */
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
+
 struct rt_scene {
     void* d_blob = nullptr;
     size_t nbytes = 0;
@@ -698,6 +706,7 @@ struct rt_context {
     uint32_t* counters = nullptr;
     size_t cap_counters = 0;
     uint32_t* error_flag = nullptr;
+    unsigned char* noalloc = nullptr; // this device's copy of `scratch` (hipGetSymbolAddress at rt_init)
     // pixel map cache
     uint32_t* pixmap = nullptr;
     uint32_t pm_w = 0, pm_h = 0, pm_tile = 0, pm_rank = 0, pm_world = 0, pm_n = 0;
@@ -898,6 +907,17 @@ int rt_init(rt_context** out, int device) {
         return RT_ERR_OOM;
     }
     hipMemset(ctx->error_flag, 0, sizeof(uint32_t));
+    {   // this device's address of the scratch array (the device is current: hipSetDevice above)
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) {
+            (void)hipGetLastError();
+            hipFree(ctx->error_flag);
+            hipStreamDestroy(ctx->stream);
+            delete ctx;
+            return RT_ERR_NO_DEVICE;
+        }
+        ctx->noalloc = (unsigned char*)p;
+    }
     if (const char* e = getenv("RT_TUNE_REFILL")) ctx->tune_refill = (uint32_t)std::max(1, std::min(64, atoi(e)));
     if (const char* e = getenv("RT_TUNE_LEAF")) ctx->tune_leaf = (uint32_t)std::max(1, std::min(64, atoi(e)));
     *out = ctx;
@@ -1049,6 +1069,49 @@ int rt_trace_first_hit(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays
     if (d_xi) hipFree(d_xi);
     if (rc == RT_OK) rc = check_error_flag(ctx);
     return rc;
+}
+
+int rt_trace_first_hit_noalloc(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays, size_t n, const double* medium_xi, rt_hit* out) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!sc || (!rays && n) || (!out && n)) return ctx_fail(ctx, RT_ERR_INVALID, "trace_first_hit_noalloc: bad argument");
+    if (n == 0) return RT_OK;
+    const size_t n_media = medium_xi ? (size_t)sc->hdr.n_media : 0;
+    const size_t per_ray = sizeof(rt_ray_d) + sizeof(rt_hit) + n_media * sizeof(double);
+    const size_t room = RT_NOALLOC_BYTES - RT_NOALLOC_HEAD - 2u * 256u; // (the three staging areas start on 256-byte boundaries)
+    if (n > room / per_ray) {
+        char msg[200];
+        snprintf(msg, sizeof msg, "trace_first_hit_noalloc: %zu rays exceed the %zu this scene's rays fit in the fixed %u-byte work area (use rt_trace_first_hit)",
+                 n, room / per_ray, (unsigned)RT_NOALLOC_BYTES);
+        return ctx_fail(ctx, RT_ERR_INVALID, msg);
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (rays[i].time < sc->hdr.valid0 || rays[i].time > sc->hdr.valid1)
+            return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "trace_first_hit_noalloc: a ray's time lies outside the interval the scene's BvhNodes over moving spheres were built for (compile with builder flag 4 for any time)");
+    RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    auto up256 = [](size_t v) { return (v + 255u) & ~(size_t)255u; };
+    unsigned char* base = ctx->noalloc; // the device address, never the array's name
+    uint32_t* d_flag = (uint32_t*)base;
+    rt_ray_d* d_rays = (rt_ray_d*)(base + RT_NOALLOC_HEAD);
+    rt_hit* d_out = (rt_hit*)((unsigned char*)d_rays + up256(n * sizeof(rt_ray_d)));
+    double* d_xi = n_media ? (double*)((unsigned char*)d_out + up256(n * sizeof(rt_hit))) : nullptr;
+    uint32_t flag = 0;
+    // the array keeps what the last call left in it: the flag must start at zero; the staging areas are overwritten
+    hipError_t e = hipMemsetAsync(d_flag, 0, RT_NOALLOC_HEAD, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, n * sizeof(rt_ray_d), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && d_xi) e = hipMemcpyAsync(d_xi, medium_xi, n * n_media * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        const uint32_t cap = sc->hdr.stack_need;
+        const size_t lds = (size_t)cap * RT_BLOCK * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_first_hit, dim3(grid_for(ctx, n, 4)), dim3(RT_BLOCK), lds, ctx->stream, sc->view, (const rt_ray_d*)d_rays, (uint32_t)n,
+                           (const double*)d_xi, d_out, cap, d_flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); return ctx_fail(ctx, RT_ERR_NO_DEVICE, "trace_first_hit_noalloc", e); }
+    if (flag) return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "traversal stack overflow on device");
+    return RT_OK;
 }
 
 int rt_generate_rays(rt_context* ctx, const rt_camera* cam, const rt_params* p, uint32_t sample, rt_ray_d* out) {
