@@ -1,8 +1,8 @@
 """Headline benchmark: rays/s (and samples/s) on the Book-2 final scene, 800x800, max depth 50, on N MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             (ranks started by torchrun)
 
 One step = one render pass: --spp samples per pixel per GPU in the job (N * spp per pixel over the whole 800x800
 image, tiles dealt round-robin to the ranks), i.e. a fixed number of paths per GPU per step (weak scaling). Inputs
@@ -26,12 +26,13 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X vector FP64 spec peak
-# Algorithmic HBM bytes k_extend_tree moves per ray segment in this layout: live-queue index read (4) + ray record
-# read (7 x f64 = 56) + hit record write (16).
-EXTEND_BYTES_PER_SEGMENT = 76
-# Whole-path compulsory path-state traffic per segment, f64 layout: extend 76; bin 4 + 16 + 4; shade reads
-# 4 + 56 + 16 + 24 (throughput) and writes 56 (next ray) + 24 + 4.
-PATH_BYTES_PER_SEGMENT = 284
+# Algorithmic HBM bytes k_extend_tree moves per ray segment in this layout: ray record read (7 x f64 = 56) + hit record
+# write (16). (Path i of a bounce is record i: no queue index is read.)
+EXTEND_BYTES_PER_SEGMENT = 72
+# Whole-path compulsory path-state traffic per segment, f64 layout: extend 72; shade reads 56 (ray) + 16 (hit) + 24
+# (throughput) and writes 56 (next ray) + 24; + 8 for the slot / pixel words that ride in the 64-byte ray records,
+# + 24 / rays-per-sample for the radiance written once per path and read once by the accumulation (~ 10).
+PATH_BYTES_PER_SEGMENT = 266
 # Work per segment under the REFERENCE's traversal (always both children, no ordering), counted by the oracle and
 # committed as tests/golden/visits.json: flops = 27 per box test (3 divides, 6 sub, 6 mul, 6 select, 6 compare) + 25 per
 # sphere + 12 per rect + 60 for the scatter; scene bytes = 32 per box test and sphere, 48 per rect.
@@ -53,27 +54,70 @@ def reference_work_per_segment(scene):
             "scene_bytes": sum(SCENE_BYTES[k] * per[k] for k in FLOPS)}
 
 
+def native_oracle():
+    """The oracle compiled -O3 -march=native ON THIS HOST (the shipped library is built for any x86-64, on another
+    machine) -> path of the library, or None when there is no compiler. About 15 s, once per bench run."""
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "oracle", "oracle.cpp")
+    out = os.path.join(tempfile.mkdtemp(prefix="rt_oracle_native_"), "liboracle_native.so")
+    cmd = ["g++", "-O3", "-march=native", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", src, "-o", out]
+    try:
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    except (OSError, subprocess.SubprocessError):
+        return None
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(desc, info, seed, target_seconds):
-    """The oracle (a restatement of the reference's CPU renderer) timed on this host's cores over a bounded sample
-    of the same workload: whole 800x800 image, as many spp as fit in about target_seconds."""
+    """The oracle (a restatement of the reference's CPU renderer, not the Rust binary) timed on ALL of this host's
+    cores over a bounded sample of the same workload: whole 800x800 image, as many spp as fit in about target_seconds."""
+    native = native_oracle()
+    if native:
+        os.environ["RT_ORACLE_SO"] = native
     import checkers as ck
     from raytracer_amd import api
-    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    cores = max(1, len(os.sched_getaffinity(0)))
     osc = ck.OracleScene(desc)
     p = api.params_from_info(info, seed=seed)
     _, st = osc.render(info.camera, p, 1, threads=cores)                       # calibration: 1 spp
-    spp = int(max(1, min(64, target_seconds / max(st.seconds, 1e-3))))
+    spp = int(max(1, min(256, target_seconds / max(st.seconds, 1e-3))))
     _, st = osc.render(info.camera, p, spp, sample_offset=1, threads=cores)
     # and as the reference runs by default: 2 worker threads over 16 row bands (main.rs:128,143-152), 1 spp
     _, st2 = osc.render(info.camera, p, 1, sample_offset=1 + spp, threads=2, jobs=16)
     return {
-        "value": st.ray_segments / st.seconds, "unit": "rays/s", "cores": cores, "kind": "port",
+        "value": st.ray_segments / st.seconds, "unit": "rays/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+        "build": "g++ -O3 -march=native -ffp-contract=off, compiled on this host" if native else
+                 "g++ -O3 -ffp-contract=off (generic x86-64 build shipped with the tree; no compiler on this host)",
         "samples_per_sec": st.camera_samples / st.seconds,
-        "sample": "oracle (C++ f64 restatement of the reference renderer, %d threads, %d row-band jobs), final_scene "
-                  "%dx%d, %d spp, depth %d: %.1f s" % (st.threads, st.jobs, info.width, info.height, spp, info.max_depth, st.seconds),
+        "sample": "oracle (C++ f64 restatement of the reference renderer, not the Rust binary; %d threads, %d row-band jobs), "
+                  "final_scene %dx%d, %d spp, depth %d: %.1f s" % (st.threads, st.jobs, info.width, info.height, spp, info.max_depth, st.seconds),
         "reference_default": {"value": st2.ray_segments / st2.seconds, "unit": "rays/s", "cores": 2,
                               "sample": "the same with the reference's default 2 workers / 16 jobs, 1 spp: %.1f s" % st2.seconds},
     }
+
+
+def launch_ranks(world):
+    """`python bench.py --gpus N` without a launcher: this process starts the N ranks (fresh children; nothing here has
+    touched a GPU), lets rank 0's JSON line through and exits with the worst exit code."""
+    have = torch.cuda.device_count()  # counts devices without initialising one
+    if have < world:
+        raise SystemExit("bench.py --gpus %d needs %d GPUs on this machine; it has %d" % (world, world, have))
+    from raytracer_amd import dist as rdist
+    rc, codes = rdist.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], world)
+    if rc != 0:
+        print("bench.py: rank exit codes %s" % codes, file=sys.stderr)
+    sys.exit(rc if 0 <= rc < 256 else 1)
 
 
 def main():
@@ -86,18 +130,25 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     args = ap.parse_args()
 
+    world = args.gpus
+    if world < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if world > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(world)  # does not return
+
     from raytracer_amd import api
     from raytracer_amd import dist as rdist
 
-    world = args.gpus
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
-        if int(os.environ.get("WORLD_SIZE", "1")) != world:
-            raise SystemExit("--gpus %d needs to be launched with torch.distributed.run --nproc-per-node %d" % (world, world))
+        if int(os.environ["WORLD_SIZE"]) != world:
+            raise SystemExit("--gpus %d but the launcher started %s ranks" % (world, os.environ["WORLD_SIZE"]))
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        rccl_ranks = dist.get_world_size()
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -186,19 +237,29 @@ def main():
         achieved = EXTEND_BYTES_PER_SEGMENT * seg_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         ref_work = reference_work_per_segment(args.scene)
         rate = segments / elapsed / world  # per GPU
-        traffic = None
+        # Counters cannot be read inside this process: they come from rocprofv3 --pmc runs of tools/gpu_round.sh, kept in
+        # profiles/ with the pass size they were taken at (counters_from).
+        traffic, counters_from = None, {}
         pmc_path = os.path.join(ROOT, "profiles", "extend_hbm_traffic.json")
         if os.path.exists(pmc_path):
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            pmc = json.load(open(pmc_path))
+            traffic = pmc.get("hbm_bytes_per_launch_corrected")
+            counters_from["traffic"] = {"file": "profiles/extend_hbm_traffic.json", "spp_per_pass": pmc.get("spp_per_pass"),
+                                        "segments_per_launch": pmc.get("segments_per_launch"),
+                                        "correction": "FETCH_SIZE x 2 (gfx950, 16-byte-per-lane streaming reads) + WRITE_SIZE"}
         valu = {}
         sq_path = os.path.join(ROOT, "profiles", "sq_counters.json")  # rocprofv3 --pmc SQ_* passes (tools/sq_summary.py)
         if os.path.exists(sq_path):
-            sq = json.load(open(sq_path)).get("k_extend_tree", {})
-            valu = {"valu_busy": sq.get("valu_busy"), "valu_lane_use": sq.get("lane_use")}
+            sqj = json.load(open(sq_path))
+            sq = sqj.get("k_extend_tree", {})
+            if sq.get("valu_busy") is not None and sq.get("lane_use") is not None:
+                valu = {"valu_busy": sq["valu_busy"], "valu_lane_use": sq["lane_use"],
+                        "valu_useful_issue_frac": sq["valu_busy"] * sq["lane_use"]}
+            counters_from["valu"] = {"file": "profiles/sq_counters.json", "spp_per_pass": sqj.get("spp_per_pass")}
         out = {
             "metric": "rays_per_sec", "value": segments / elapsed, "unit": "rays/s",
             "samples_per_sec": samples / elapsed,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "rays_per_sec_per_gpu": rate, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s, %dx%d, max depth %d, %d spp per step (%d per GPU), scene seed 0x5EED0001, render seed 0x5EED0002" %
                                    ("Book-2 final scene (final_scene, main.rs:576-688)" if args.scene == "final_scene" else "scene " + args.scene,
@@ -209,12 +270,18 @@ def main():
             "image_sha256": hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest(),
             "image_mean": float(img.mean() / (step_index * spp_step)),
             "roofline": {
-                "kernel": "k_extend_tree", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                # achieved / peak / frac: the kernel's ALGORITHMIC path-state bytes over its HIP-event time against the HBM
+                # peak (measured here). The kernel is not bound by HBM: the scene sits in L2 / LDS, and what limits it is
+                # f64 VALU issue under divergence - valu_busy x valu_lane_use, from the SQ counters (counters_from).
+                "kernel": "k_extend_tree", "bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_segment": EXTEND_BYTES_PER_SEGMENT, "segments_per_launch": seg_per_launch,
                 "avg_launch_ms": avg_ms, "launches": int(stats.extend_launches), **valu,
-                "note": "cache-resident scene: the kernel is bound by f64 VALU issue and latency under divergence, "
-                        "not by HBM; the HBM figure is the compulsory path-state traffic only",
+                "counters_from": counters_from,
+                "note": "cache-resident scene: bound by f64 VALU issue and latency under divergence (valu_busy x "
+                        "valu_lane_use = the share of VALU issue slots doing useful lanes), not by HBM; achieved/frac "
+                        "are the compulsory path-state bytes against the HBM peak; traffic = HBM bytes per launch from "
+                        "FETCH_SIZE x 2 + WRITE_SIZE at the pass size named in counters_from",
             },
             "path_hbm_frac": PATH_BYTES_PER_SEGMENT * rate / 1e9 / HBM_PEAK_GBS,
             # the same rate priced in the reference traversal's arithmetic and scene reads (the GPU path does less of both)

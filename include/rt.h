@@ -156,7 +156,8 @@ typedef struct {
 typedef struct {
     uint64_t camera_samples;   /* iterations of main.rs:161-167 */
     uint64_t ray_segments;     /* world.hit calls issued by ray_color (main.rs:56), primary included */
-    uint64_t medium_tests;     /* ConstantMedium::hit calls (constant_medium.rs:25), not counted as rays */
+    uint64_t medium_tests;     /* ConstantMedium::hit calls (constant_medium.rs:25) the reference makes for these segments with its media in the
+                                  world list: ray_segments x n_media. Not counted as rays; the kernels skip many of them */
     uint64_t passes;
     double seconds_render;     /* host wall clock around the device work */
     /* HIP-event sums per kernel when profile = 1. extend_ms = closest-hit search (k_extend_tree); shade_main_ms =
@@ -195,6 +196,15 @@ int rt_scene_build_tree_device(rt_context*, rt_scene*, rt_tree_stats* stats /* n
  * NULL = ConstantMedium objects never hit. */
 int rt_trace_first_hit(rt_context*, const rt_scene*, const rt_ray_d* rays, size_t n, const double* medium_xi,
                        rt_hit* out);
+
+/* The same query answered by the kernel the renderer spends its time in (k_extend_tree: persistent waves, node cache
+ * in LDS, leaf rounds, queue dealt in pieces) instead of the one-lane-one-ray kernel of rt_trace_first_hit: same arguments,
+ * same results bit for bit except the winner of an exact tie. Exists so that the parity gate of hittable_list.rs:40-53 /
+ * bvh.rs:112-122 can be put on the kernel that is benchmarked; also the faster of the two for large batches.
+ * variant: bit 0 = use the instantiation with exact f64 box tests (aabb.rs:35-75) even if no node of the scene needs them,
+ * bit 1 = the one with the general ConstantMedium boundary code even if every medium is bounded by a sphere. */
+int rt_trace_first_hit_wavefront(rt_context*, const rt_scene*, const rt_ray_d* rays, size_t n, const double* medium_xi,
+                                 rt_hit* out, uint32_t variant);
 
 /* rt_trace_first_hit without any allocation. No counterpart in the reference: it is for callers that cannot allocate
  * device memory while they run - code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.

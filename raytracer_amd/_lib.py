@@ -104,6 +104,7 @@ PROTOTYPES = {
     "rt_scene_free": (None, [_P, _P]),
     "rt_scene_build_tree_device": (C.c_int, [_P, _P, C.POINTER(rt_tree_stats)]),
     "rt_trace_first_hit": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P]),
+    "rt_trace_first_hit_wavefront": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, C.c_uint32]),
     "rt_trace_first_hit_noalloc": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P]),
     "rt_generate_rays": (C.c_int, [_P, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_uint32, _P]),
     "rt_render_accumulate": (C.c_int, [_P, _P, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_uint32, C.c_uint32, _P,

@@ -200,15 +200,19 @@ class Context:
         self._chk(lib.rt_scene_build_tree_device(self._c, scene._h, C.byref(st)))
         return st
 
-    def trace_first_hit(self, scene, rays, medium_xi=None, noalloc=False):
-        """noalloc=True: through rt_trace_first_hit_noalloc (fixed work area, limited batch, no device allocation)."""
+    def trace_first_hit(self, scene, rays, medium_xi=None, noalloc=False, wavefront=None):
+        """noalloc=True: through rt_trace_first_hit_noalloc (fixed work area, limited batch, no device allocation).
+        wavefront=v (0..3): through rt_trace_first_hit_wavefront, i.e. the renderer's traversal kernel, variant v."""
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
         out = np.zeros(len(rays), dtype=HIT_DTYPE)
         xi = None
         if medium_xi is not None:
             xi = np.ascontiguousarray(medium_xi, dtype=np.float64)
-        fn = lib.rt_trace_first_hit_noalloc if noalloc else lib.rt_trace_first_hit
-        self._chk(fn(self._c, scene._h, rays.ctypes.data, len(rays), xi.ctypes.data if xi is not None else None, out.ctypes.data))
+        args = (self._c, scene._h, rays.ctypes.data, len(rays), xi.ctypes.data if xi is not None else None, out.ctypes.data)
+        if wavefront is not None:
+            self._chk(lib.rt_trace_first_hit_wavefront(*args, int(wavefront)))
+        else:
+            self._chk((lib.rt_trace_first_hit_noalloc if noalloc else lib.rt_trace_first_hit)(*args))
         return out
 
     def generate_rays(self, camera, params, sample):

@@ -51,7 +51,9 @@ def build_oracle(force=False):
     src = os.path.join(ROOT, "oracle", "oracle.cpp")
     if not force and _newer(ORACLE_SO, [src, os.path.join(ROOT, "include", "rt.h")]):
         return ORACLE_SO
-    _run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", src, "-o", ORACLE_SO])
+    # (no -march=native: the library is built in one machine and run on another; bench.py's CPU baseline compiles its own
+    # -march=native copy on the host it times)
+    _run(["g++", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", src, "-o", ORACLE_SO])
     return ORACLE_SO
 
 

@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -142,6 +143,16 @@ struct PhiloxXi { // the uniform a ConstantMedium draws (constant_medium.rs:53) 
 struct ArrayXi { // injected uniforms for rt_trace_first_hit
     const double* row;
     __device__ double operator()(uint32_t medium_index) const { return row[medium_index]; }
+};
+template <bool ONLY_SPHERE_MEDIA>
+struct ArrayXiOf : ArrayXi { static constexpr bool only_sphere_media = ONLY_SPHERE_MEDIA; };
+// Caller-supplied rays for k_extend_tree<.., QUERY = true> (rt_trace_first_hit_wavefront): ray i is "path" i, with its own
+// t_min / t_max and its own row of medium uniforms; the closest hit goes to hit[i].
+struct QueryBatch {
+    const rt_ray_d* rays;
+    const double* xi_rows; // n * n_media uniforms, or null: media never hit
+    RtHitLite* hit;
+    uint32_t n;
 };
 
 // Hands every thread with `take` set a distinct position counted from *counter: ONE atomic per workgroup (a single
@@ -307,15 +318,28 @@ __device__ unsigned long long g_phase[4][48];
 #endif
 // EXACT_NODES = false: the scene has no node whose box tests must reproduce the reference's f64 arithmetic.
 // SPHERE_MEDIA = true: every ConstantMedium of the scene is bounded by a plain sphere.
-template <bool EXACT_NODES, bool SPHERE_MEDIA>
+// QUERY = true: the rays are a caller's batch (`qb`) instead of the live paths of bounce `it`: same scheduling, same
+// node cache, same leaf rounds; per-ray t_min / t_max and injected medium uniforms.
+template <bool EXACT_NODES, bool SPHERE_MEDIA, bool QUERY>
 __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
                                                                uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_min,
-                                                               uint32_t n_cached) {
+                                                               uint32_t n_cached, QueryBatch qb) {
     extern __shared__ uint4 lds_tree[]; // stack_cap * blockDim.x words of stack, n_cached node records, the queue counter
     const PathRay* rays = pb.ray[it & 1u];
-    const LiveSet alive_paths = live_set(qs.counters + it * RT_COUNTER_STRIDE, qs.bucket_cap);
+    LiveSet alive_paths;
+    alive_paths.front = 0u; alive_paths.back = 0u; alive_paths.cap = 0u;
+    if (QUERY) alive_paths.front = qb.n; else alive_paths = live_set(qs.counters + it * RT_COUNTER_STRIDE, qs.bucket_cap);
     const uint32_t n = alive_paths.n();
     if (n == 0u) return;
+    typedef typename std::conditional<QUERY, ArrayXiOf<SPHERE_MEDIA>, PhiloxXi<SPHERE_MEDIA>>::type Xi;
+    const bool skip_media = QUERY && qb.xi_rows == nullptr;
+    double t_min = 0.001; // main.rs:56; a query ray brings its own
+    auto xi_of = [&](PathId id, uint32_t path) -> Xi {
+        Xi xi;
+        if constexpr (QUERY) { xi.row = qb.xi_rows ? qb.xi_rows + (size_t)path * sc.n_media : nullptr; }
+        else { xi.pi = &pi; xi.id = id; xi.bounce = it; }
+        return xi;
+    };
     // queue positions handed out in this workgroup so far: the 16 bytes behind the node records
     uint32_t& blk_taken = *(uint32_t*)(lds_tree + (size_t)stack_cap * blockDim.x / 4u + (size_t)n_cached * 4u);
     if (threadIdx.x == 0u) blk_taken = 0u;
@@ -370,14 +394,19 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
                 const unsigned long long i = index_of(v0 + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)));
                 if (i < n) {
                     path = alive_paths.record((uint32_t)i);
-                    s.r = load_ray(rays + path, id);
                     s.best.t = RT_INF; s.best.ref = RT_REF_NONE; s.best.aux = 0u;
+                    if constexpr (QUERY) {
+                        QueryRay q;
+                        q.q = qb.rays + path;
+                        s.r = q();
+                        t_min = q.q->tmin; s.best.t = q.q->tmax;
+                    } else {
+                        s.r = load_ray(rays + path, id);
+                    }
                     // the world entries every ray is tested against, by the lanes that just took a ray, in lock step
                     HeldRay held;
                     held.r = &s.r;
-                    PhiloxXi<SPHERE_MEDIA> xi;
-                    xi.pi = &pi; xi.id = id; xi.bounce = it;
-                    rt_extend_flat(sc, held, 0.001, s.best, xi, false);
+                    rt_extend_flat(sc, held, t_min, s.best, xi_of(id, path), skip_media);
                     s.slab = rt_slab_of(s.r, sc.node_extent);
                     s.cur = sc.world_tree;
                     st.sp = 0u;
@@ -394,10 +423,10 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             if (__ballot(at_node) == 0ull) break;
             if ((uint32_t)__popcll(__ballot(active && !at_node)) >= leaf_min) break;
             RT_PHASE_ADD(3, 1); RT_PHASE_ADD(4, __popcll(__ballot(at_node)));
-            if (at_node) rt_trav_node_step<EXACT_NODES>(nodes, s, st, 0.001);
+            if (at_node) rt_trav_node_step<EXACT_NODES>(nodes, s, st, t_min);
             // a second step before the next look at the wave: the two ballots above cost a sixth of a step (-3.6 % kernel
             // time; a third and fourth step bring nothing more)
-            if (active && RT_REF_TYPE(s.cur) == RT_REF_NODE) rt_trav_node_step<EXACT_NODES>(nodes, s, st, 0.001);
+            if (active && RT_REF_TYPE(s.cur) == RT_REF_NODE) rt_trav_node_step<EXACT_NODES>(nodes, s, st, t_min);
         }
         // ---- one non-node reference for every lane that holds one ----
 #ifdef RT_PHASE_STATS
@@ -412,16 +441,20 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
         }
 #endif
         if (active && s.cur != RT_REF_NONE && RT_REF_TYPE(s.cur) != RT_REF_NODE) {
-            SlotRay ray_of;
-            ray_of.rec = rays + path;
-            PhiloxXi<SPHERE_MEDIA> xi;
-            xi.pi = &pi; xi.id = id; xi.bounce = it;
-            rt_trav_visit(sc, s, st, 0.001, xi, false, ray_of);
+            if constexpr (QUERY) {
+                QueryRay ray_of;
+                ray_of.q = qb.rays + path;
+                rt_trav_visit(sc, s, st, t_min, xi_of(id, path), skip_media, ray_of);
+            } else {
+                SlotRay ray_of;
+                ray_of.rec = rays + path;
+                rt_trav_visit(sc, s, st, t_min, xi_of(id, path), skip_media, ray_of);
+            }
         }
         if (active && s.cur == RT_REF_NONE) { // finished: publish the closest hit
             RtHitLite h;
             h.t = s.best.t; h.ref = s.best.ref; h.aux = s.best.aux;
-            pb.hit[path] = h;
+            (QUERY ? qb.hit : pb.hit)[path] = h;
             active = false;
         }
     }
@@ -621,6 +654,26 @@ __global__ void __launch_bounds__(RT_BLOCK) k_set_u32(uint32_t* p, uint32_t v) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *p = v;
 }
 
+// What world.hit leaves in rec (hittable.rs:9-18) for closest hit `h` of ray `r`, as the record the C ABI reports.
+__device__ inline rt_hit full_hit_record(const DScene& sc, const Ray& r, double t_max, const RtHitLite& h) {
+    rt_hit o;
+    memset(&o, 0, sizeof o);
+    if (h.ref == RT_REF_NONE) {
+        o.prim_id = RT_MISS;
+        o.t = t_max;
+    } else {
+        const HitRec rec = rt_reconstruct(sc, r, h, true);
+        o.t = rec.t;
+        o.prim_id = rec.src_id;
+        o.flags = RT_HIT_FLAG_HIT | (rec.front_face ? RT_HIT_FLAG_FRONT : 0u) | (h.aux << 4);
+        o.px = rec.p.x; o.py = rec.p.y; o.pz = rec.p.z;
+        o.nx = rec.normal.x; o.ny = rec.normal.y; o.nz = rec.normal.z;
+        o.u = rec.u; o.v = rec.v;
+        o.material_id = rec.material;
+    }
+    return o;
+}
+
 // Hittable::hit of the world list for caller-supplied rays, with the full HitRecord rebuilt.
 __global__ void __launch_bounds__(RT_BLOCK) k_first_hit(DScene sc, const rt_ray_d* rays, uint32_t n, const double* xi_rows,
                                                         rt_hit* out, uint32_t stack_cap, uint32_t* error_flag) {
@@ -639,22 +692,16 @@ __global__ void __launch_bounds__(RT_BLOCK) k_first_hit(DScene sc, const rt_ray_
         xi.row = xi_rows ? xi_rows + (size_t)i * sc.n_media : nullptr;
         st.sp = 0u;
         const RtHitLite h = rt_extend(sc, ray_of, q.tmin, q.tmax, st, xi, xi_rows == nullptr);
-        rt_hit o;
-        memset(&o, 0, sizeof o);
-        if (h.ref == RT_REF_NONE) {
-            o.prim_id = RT_MISS;
-            o.t = q.tmax;
-        } else {
-            const HitRec rec = rt_reconstruct(sc, r, h, true);
-            o.t = rec.t;
-            o.prim_id = rec.src_id;
-            o.flags = RT_HIT_FLAG_HIT | (rec.front_face ? RT_HIT_FLAG_FRONT : 0u) | (h.aux << 4);
-            o.px = rec.p.x; o.py = rec.p.y; o.pz = rec.p.z;
-            o.nx = rec.normal.x; o.ny = rec.normal.y; o.nz = rec.normal.z;
-            o.u = rec.u; o.v = rec.v;
-            o.material_id = rec.material;
-        }
-        out[i] = o;
+        out[i] = full_hit_record(sc, r, q.tmax, h);
+    }
+}
+
+// The second half of rt_trace_first_hit_wavefront: HitRecords from the closest hits k_extend_tree<.., QUERY> found.
+__global__ void __launch_bounds__(RT_BLOCK) k_query_finish(DScene sc, QueryBatch qb, rt_hit* out) {
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < qb.n; i += gridDim.x * RT_BLOCK) {
+        QueryRay ray_of;
+        ray_of.q = qb.rays + i;
+        out[i] = full_hit_record(sc, ray_of(), ray_of.q->tmax, qb.hit[i]);
     }
 }
 
@@ -869,6 +916,42 @@ struct EventTimer { // brackets launches with events when profiling; sums are re
     }
 };
 
+// How k_extend_tree is launched on a scene: which instantiation, and what its one workgroup per CU keeps in LDS.
+typedef void (*ExtendKernel)(DScene, PassInfo, PathBufs, QueueSet, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, QueryBatch);
+struct ExtendLaunch {
+    ExtendKernel kernel;
+    size_t lds;
+    uint32_t stack_cap, n_cached, refill_min, leaf_min;
+};
+// `force`: bit 0 = the instantiation with exact f64 box tests even if the scene has no node that needs them, bit 1 = the
+// one with the general medium-boundary code even if every medium is bounded by a sphere (both are valid for any scene).
+int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t force, ExtendLaunch* out) {
+    const uint32_t stack_cap = sc->hdr.stack_need;
+    // Persistent waves, one workgroup per CU: its LDS holds the traversal stacks and, in what is left, the first
+    // records of the node array (the compiler numbers nodes breadth-first, so these are the ones nearest the root).
+    const size_t lds_stack_bytes = (size_t)stack_cap * RT_TREE_BLOCK * sizeof(uint32_t);
+    if (lds_stack_bytes + 16 > ctx->lds_per_block) return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "render: traversal stacks exceed the LDS of a workgroup");
+    const uint32_t n_cached = (uint32_t)std::min<size_t>(sc->hdr.nodes.count, (ctx->lds_per_block - lds_stack_bytes - 16) / sizeof(RtNode));
+    const size_t lds = lds_stack_bytes + (size_t)n_cached * sizeof(RtNode) + 16;
+    const bool exact_nodes = sc->hdr.n_exact_nodes != 0u || (force & 1u);
+    const bool sphere_media = sc->sphere_media && !(force & 2u);
+    // Scheduling thresholds of the traversal kernel, from sweeps (tools/tune.sh): trees walked nearest child first like
+    // earlier refills and leaf rounds than trees that replay the reference's order (long forced descents).
+    out->refill_min = ctx->tune_refill ? ctx->tune_refill : (exact_nodes ? 44u : 36u);
+    out->leaf_min = ctx->tune_leaf ? ctx->tune_leaf : (exact_nodes ? 36u : 30u);
+    static const ExtendKernel table[2][2][2] = {
+        {{k_extend_tree<false, false, false>, k_extend_tree<false, false, true>}, {k_extend_tree<false, true, false>, k_extend_tree<false, true, true>}},
+        {{k_extend_tree<true, false, false>, k_extend_tree<true, false, true>}, {k_extend_tree<true, true, false>, k_extend_tree<true, true, true>}}};
+    out->kernel = table[exact_nodes][sphere_media][query];
+    if (lds > 65536)
+        RT_HIP(hipFuncSetAttribute((const void*)out->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size of k_extend_tree");
+    if (getenv("RT_DEBUG"))
+        fprintf(stderr, "rt: lds_per_block %zu, stack_need %u, nodes %llu, cached %u, lds %zu\n", ctx->lds_per_block, stack_cap,
+                (unsigned long long)sc->hdr.nodes.count, n_cached, lds);
+    out->lds = lds; out->stack_cap = stack_cap; out->n_cached = n_cached;
+    return RT_OK;
+}
+
 template <uint32_t BUCKET>
 void launch_shade(rt_context* ctx, const rt_scene* sc, const PassInfo& pi, const PathBufs& pb, const QueueSet& qs, uint32_t it,
                   uint32_t grid, EventTimer& tm) {
@@ -1071,6 +1154,56 @@ int rt_trace_first_hit(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays
     return rc;
 }
 
+int rt_trace_first_hit_wavefront(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays, size_t n, const double* medium_xi,
+                                 rt_hit* out, uint32_t variant) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!sc || (!rays && n) || (!out && n) || n > 0x7FFFFFFFu || variant > 3u) return ctx_fail(ctx, RT_ERR_INVALID, "trace_first_hit_wavefront: bad argument");
+    if (n == 0) return RT_OK;
+    for (size_t i = 0; i < n; ++i)
+        if (rays[i].time < sc->hdr.valid0 || rays[i].time > sc->hdr.valid1)
+            return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "trace_first_hit_wavefront: a ray's time lies outside the interval the scene's BvhNodes over moving spheres were built for (compile with builder flag 4 for any time)");
+    RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    ExtendLaunch xl;
+    int rc = extend_launch_of(ctx, sc, true, variant, &xl);
+    if (rc != RT_OK) return rc;
+    rt_ray_d* d_rays = nullptr;
+    rt_hit* d_out = nullptr;
+    double* d_xi = nullptr;
+    RtHitLite* d_lite = nullptr;
+    const size_t xi_bytes = medium_xi ? n * (size_t)sc->hdr.n_media * sizeof(double) : 0;
+    hipError_t e = hipMalloc((void**)&d_rays, n * sizeof(rt_ray_d));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, n * sizeof(rt_hit));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_lite, n * sizeof(RtHitLite));
+    if (e == hipSuccess && xi_bytes) e = hipMalloc((void**)&d_xi, xi_bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, n * sizeof(rt_ray_d), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && xi_bytes) e = hipMemcpyAsync(d_xi, medium_xi, xi_bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        QueryBatch qb;
+        qb.rays = d_rays; qb.xi_rows = d_xi; qb.hit = d_lite; qb.n = (uint32_t)n;
+        PassInfo pi;
+        memset(&pi, 0, sizeof pi);
+        PathBufs pb;
+        memset(&pb, 0, sizeof pb);
+        QueueSet qs;
+        memset(&qs, 0, sizeof qs);
+        qs.error_flag = ctx->error_flag;
+        const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min<size_t>((n + RT_TREE_BLOCK - 1) / RT_TREE_BLOCK, (size_t)ctx->n_cu));
+        hipLaunchKernelGGL(xl.kernel, dim3(grid), dim3(RT_TREE_BLOCK), xl.lds, ctx->stream, sc->view, pi, pb, qs, 0u, xl.stack_cap,
+                           xl.refill_min, xl.leaf_min, xl.n_cached, qb);
+        hipLaunchKernelGGL(k_query_finish, dim3(grid_for(ctx, n, 8)), dim3(RT_BLOCK), 0, ctx->stream, sc->view, qb, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); rc = ctx_fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_NO_DEVICE, "trace_first_hit_wavefront", e); }
+    if (d_rays) hipFree(d_rays);
+    if (d_out) hipFree(d_out);
+    if (d_lite) hipFree(d_lite);
+    if (d_xi) hipFree(d_xi);
+    if (rc == RT_OK) rc = check_error_flag(ctx);
+    return rc;
+}
+
 int rt_trace_first_hit_noalloc(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays, size_t n, const double* medium_xi, rt_hit* out) {
     if (!ctx) return RT_ERR_INVALID;
     if (!sc || (!rays && n) || (!out && n)) return ctx_fail(ctx, RT_ERR_INVALID, "trace_first_hit_noalloc: bad argument");
@@ -1176,27 +1309,15 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
     // compiler gave moving spheres in the tree hold for all of it, those spheres need no lock-step test
     if (cam->time0 >= sc->hdr.shutter0 && cam->time1 <= sc->hdr.shutter1 && cam->time0 <= cam->time1) local.view.world_flat = sc->hdr.world_flat;
 
-    const uint32_t stack_cap = sc->hdr.stack_need;
-    // Persistent waves, one workgroup per CU: its LDS holds the traversal stacks and, in what is left, the first
-    // records of the node array (the compiler numbers nodes breadth-first, so these are the ones nearest the root).
-    const size_t lds_stack_bytes = (size_t)stack_cap * RT_TREE_BLOCK * sizeof(uint32_t);
-    if (lds_stack_bytes + 16 > ctx->lds_per_block) return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "render: traversal stacks exceed the LDS of a workgroup");
-    const uint32_t n_cached = (uint32_t)std::min<size_t>(sc->hdr.nodes.count, (ctx->lds_per_block - lds_stack_bytes - 16) / sizeof(RtNode));
-    const size_t lds = lds_stack_bytes + (size_t)n_cached * sizeof(RtNode) + 16;
-    const bool exact_nodes = sc->hdr.n_exact_nodes != 0u;
-    // Scheduling thresholds of the traversal kernel, from sweeps (tools/tune.sh): trees walked nearest child first like
-    // earlier refills and leaf rounds than trees that replay the reference's order (long forced descents).
-    const uint32_t refill_min = ctx->tune_refill ? ctx->tune_refill : (exact_nodes ? 44u : 36u);
-    const uint32_t leaf_min = ctx->tune_leaf ? ctx->tune_leaf : (exact_nodes ? 36u : 30u);
-    typedef void (*ExtendKernel)(DScene, PassInfo, PathBufs, QueueSet, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
-    const ExtendKernel k_extend = exact_nodes ? (sc->sphere_media ? k_extend_tree<true, true> : k_extend_tree<true, false>)
-                                              : (sc->sphere_media ? k_extend_tree<false, true> : k_extend_tree<false, false>);
-    if (lds > 65536)
-        RT_HIP(hipFuncSetAttribute((const void*)k_extend, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size of k_extend_tree");
+    ExtendLaunch xl;
+    rc = extend_launch_of(ctx, sc, false, 0u, &xl);
+    if (rc != RT_OK) return rc;
+    const uint32_t stack_cap = xl.stack_cap, refill_min = xl.refill_min, leaf_min = xl.leaf_min, n_cached = xl.n_cached;
+    const size_t lds = xl.lds;
+    const ExtendKernel k_extend = xl.kernel;
     const uint32_t extend_blocks_per_cu = 1u;
-    if (getenv("RT_DEBUG"))
-        fprintf(stderr, "rt: lds_per_block %zu, stack_need %u, nodes %llu, cached %u, lds %zu\n", ctx->lds_per_block, stack_cap,
-                (unsigned long long)sc->hdr.nodes.count, n_cached, lds);
+    QueryBatch no_query;
+    no_query.rays = nullptr; no_query.xi_rows = nullptr; no_query.hit = nullptr; no_query.n = 0u;
     const size_t n_counters = (size_t)(p->max_depth + 2) * RT_COUNTER_STRIDE;
     std::vector<uint32_t> host_counters(n_counters);
 
@@ -1224,7 +1345,7 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
         for (uint32_t it = 0; it < p->max_depth; ++it) {
             a = tm.begin();
             hipLaunchKernelGGL(k_extend, dim3(g_ext), dim3(RT_TREE_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it, stack_cap,
-                               refill_min, leaf_min, n_cached);
+                               refill_min, leaf_min, n_cached, no_query);
             tm.end(a, 1);
             a = tm.begin();
             hipLaunchKernelGGL(k_shade_main, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);

@@ -7,11 +7,46 @@ gathered image is bit-identical for every world size.
 
 Collectives: one broadcast of the compiled scene blob from rank 0, one all_gather of the per-rank pixel sums.
 """
+import os
+import socket
+import subprocess
+import sys
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
 DEFAULT_TILE = 32
+
+
+def spawn_ranks(script, argv, world, extra_env=None, grace=30.0):
+    """One fresh child process per rank running `script argv...` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set the way torch.distributed.run sets them (rendezvous on 127.0.0.1, a free port). The children inherit
+    stdout and stderr, so what rank 0 prints is what the caller's caller reads. Returns the worst exit code. When a
+    rank fails the others may wait for it in a collective for ever: they get `grace` seconds, then are ended (by pid).
+    The caller must not have initialised a GPU: the children are started with fork + exec."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env))
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        if failed_at is None and any(p.returncode not in (None, 0) for p in procs):
+            failed_at = time.monotonic()
+        if failed_at is not None and time.monotonic() - failed_at > grace:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    codes = [p.returncode for p in procs]
+    bad = [c for c in codes if c != 0]
+    return (max(bad, key=abs) if bad else 0), codes
 
 
 def local_pixel_indices(width, height, tile, rank, world):
@@ -46,15 +81,25 @@ def gather_image(rgb_sum, width, height, tile, rank, world):
     """rgb_sum: this rank's (height*width*3) f64 tensor with its own tiles filled. Returns the full image on every
     rank: each rank contributes only its own pixels (padded to a common length), one all_gather."""
     flat = rgb_sum.view(-1, 3)
-    counts = [len(local_pixel_indices(width, height, tile, r, world)) for r in range(world)]
+    index = _rank_indices(width, height, tile, world, flat.device)
+    counts = [len(i) for i in index]
     longest = max(counts)
-    mine = torch.from_numpy(local_pixel_indices(width, height, tile, rank, world)).to(flat.device)
     send = torch.zeros((longest, 3), dtype=flat.dtype, device=flat.device)
-    send[:counts[rank]] = flat.index_select(0, mine)
+    send[:counts[rank]] = flat.index_select(0, index[rank])
     recv = torch.empty((world, longest, 3), dtype=flat.dtype, device=flat.device)
     dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
     full = torch.zeros_like(flat)
     for r in range(world):
-        idx = torch.from_numpy(local_pixel_indices(width, height, tile, r, world)).to(flat.device)
-        full.index_copy_(0, idx, recv[r, :counts[r]])
+        full.index_copy_(0, index[r], recv[r, :counts[r]])
     return full.view(height, width, 3)
+
+
+_index_cache = {}
+
+
+def _rank_indices(width, height, tile, world, device):
+    """Every rank's pixel index list as tensors on `device`, built once per (image, tile, world, device)."""
+    key = (width, height, tile, world, str(device))
+    if key not in _index_cache:
+        _index_cache[key] = [torch.from_numpy(local_pixel_indices(width, height, tile, r, world)).to(device) for r in range(world)]
+    return _index_cache[key]
