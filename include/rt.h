@@ -84,8 +84,9 @@ int rt_rotate_y(rt_builder*, int child, double angle_degrees);                  
 int rt_constant_medium(rt_builder*, int boundary, double density, double r, double g, double b); /* constant_medium.rs:15 */
 int rt_list_new(rt_builder*);                                                               /* hittable_list.rs:27 */
 int rt_list_add(rt_builder*, int list, int child);                                          /* hittable_list.rs:15 */
-/* BvhNode::new_(list, time0, time1) (bvh.rs:68-71). Sorts `list` in place like the reference.
- * RT_ERR_PANIC if a member has no bounding box (bvh.rs:58,77). */
+/* BvhNode::new_(list, time0, time1) (bvh.rs:68-71). Sorts `list` in place like the reference - except with builder flag
+ * bit 3 where all boxes bound their contents: the node then only keeps its box and the list keeps its order (nothing reads
+ * the order of a list whose tree the device will build). RT_ERR_PANIC if a member has no bounding box (bvh.rs:58,77). */
 int rt_bvh(rt_builder*, int list, double time0, double time1);
 
 /* Flatten the object graph below `world_list` into a relocatable blob (malloc'ed; free with rt_free).

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+# (RT_HIP_LIB: another build of the same library, e.g. one with the debug counters of -DRT_PHASE_STATS)
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")
 
 RT_OK, RT_ERR_INVALID, RT_ERR_UNSUPPORTED, RT_ERR_NO_DEVICE, RT_ERR_OOM, RT_ERR_PANIC = 0, -1, -2, -3, -4, -5
 RT_MISS = 0xFFFFFFFF

@@ -1217,6 +1217,8 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
 }
 
 // ---- C entry points ---------------------------------------------------------------------------------------
+// Nothing may unwind across the C ABI: the entry points are function-try-blocks that end in this.
+#define RT_ABI_CATCH catch (const std::bad_alloc&) { return RT_ERR_OOM; } catch (...) { return RT_ERR_INVALID; }
 extern "C" {
 
 rt_builder* rt_builder_new(uint64_t seed) {
@@ -1228,23 +1230,23 @@ rt_builder* rt_builder_new(uint64_t seed) {
 }
 void rt_builder_free(rt_builder* b) { delete b; }
 const char* rt_builder_last_error(const rt_builder* b) { return b ? b->error.c_str() : "null builder"; }
-int rt_builder_set_flags(rt_builder* b, uint32_t flags) {
+int rt_builder_set_flags(rt_builder* b, uint32_t flags) try {
     if (!b) return RT_ERR_INVALID;
     b->flags = flags;
     log_fmt(b->log, "flags %u\n", flags);
     return RT_OK;
-}
+} RT_ABI_CATCH
 void rt_free(void* p) { free(p); }
 
-int rt_tex_solid(rt_builder* b, double r, double g, double bl) {
+int rt_tex_solid(rt_builder* b, double r, double g, double bl) try {
     if (!b) return RT_ERR_INVALID;
     TexRec t; t.type = RT_TEX_SOLID; t.p[0] = r; t.p[1] = g; t.p[2] = bl;
     b->texs.push_back(t);
     int id = (int)b->texs.size() - 1;
     log_fmt(b->log, "tex_solid %d %a %a %a\n", id, r, g, bl);
     return id;
-}
-int rt_tex_checker(rt_builder* b, int even_tex, int odd_tex) {
+} RT_ABI_CATCH
+int rt_tex_checker(rt_builder* b, int even_tex, int odd_tex) try {
     if (!b) return RT_ERR_INVALID;
     if (!b->valid_tex(even_tex) || !b->valid_tex(odd_tex)) return b->fail(RT_ERR_INVALID, "checker: bad texture handle");
     TexRec t; t.type = RT_TEX_CHECKER; t.a = even_tex; t.b = odd_tex;
@@ -1252,8 +1254,8 @@ int rt_tex_checker(rt_builder* b, int even_tex, int odd_tex) {
     int id = (int)b->texs.size() - 1;
     log_fmt(b->log, "tex_checker %d %d %d\n", id, even_tex, odd_tex);
     return id;
-}
-int rt_tex_noise(rt_builder* b, double scale) {
+} RT_ABI_CATCH
+int rt_tex_noise(rt_builder* b, double scale) try {
     if (!b) return RT_ERR_INVALID;
     TexRec t; t.type = RT_TEX_NOISE; t.p[0] = scale;
     // Perlin::init (perlin.rs:46-54): 256 un-normalised gradients from random_range(-1,1), then three
@@ -1277,8 +1279,8 @@ int rt_tex_noise(rt_builder* b, double scale) {
     for (int32_t v : b->texs.back().perlin_perm) log_fmt(b->log, " %d", v);
     log_fmt(b->log, "\n");
     return id;
-}
-int rt_tex_image(rt_builder* b, const uint8_t* rgb8, uint32_t width, uint32_t height) {
+} RT_ABI_CATCH
+int rt_tex_image(rt_builder* b, const uint8_t* rgb8, uint32_t width, uint32_t height) try {
     if (!b) return RT_ERR_INVALID;
     if (!rgb8 || width == 0 || height == 0) return b->fail(RT_ERR_INVALID, "image: empty");
     TexRec t; t.type = RT_TEX_IMAGE; t.width = width; t.height = height;
@@ -1289,59 +1291,59 @@ int rt_tex_image(rt_builder* b, const uint8_t* rgb8, uint32_t width, uint32_t he
     log_raw(b->log, rgb8, (size_t)width * height * 3);
     log_fmt(b->log, "\n");
     return id;
-}
+} RT_ABI_CATCH
 
 static int add_mat(rt_builder* b, uint32_t type, int tex, double p0, double p1, double p2, double p3) {
     MatRec m; m.type = type; m.tex = tex; m.p[0] = p0; m.p[1] = p1; m.p[2] = p2; m.p[3] = p3;
     b->mats.push_back(m);
     return (int)b->mats.size() - 1;
 }
-int rt_mat_lambertian(rt_builder* b, int tex) {
+int rt_mat_lambertian(rt_builder* b, int tex) try {
     if (!b) return RT_ERR_INVALID;
     if (!b->valid_tex(tex)) return b->fail(RT_ERR_INVALID, "lambertian: bad texture handle %d", tex);
     int id = add_mat(b, RT_MAT_LAMBERTIAN, tex, 0, 0, 0, 0);
     log_fmt(b->log, "mat_lambertian %d %d\n", id, tex);
     return id;
-}
-int rt_mat_metal(rt_builder* b, double r, double g, double bl, double fuzz) {
+} RT_ABI_CATCH
+int rt_mat_metal(rt_builder* b, double r, double g, double bl, double fuzz) try {
     if (!b) return RT_ERR_INVALID;
     double f1 = fuzz;
     if (f1 > 1.0) f1 = 1.0; // material.rs:69-72
     int id = add_mat(b, RT_MAT_METAL, -1, r, g, bl, f1);
     log_fmt(b->log, "mat_metal %d %a %a %a %a\n", id, r, g, bl, fuzz);
     return id;
-}
-int rt_mat_dielectric(rt_builder* b, double ir) {
+} RT_ABI_CATCH
+int rt_mat_dielectric(rt_builder* b, double ir) try {
     if (!b) return RT_ERR_INVALID;
     int id = add_mat(b, RT_MAT_DIELECTRIC, -1, ir, 0, 0, 0);
     log_fmt(b->log, "mat_dielectric %d %a\n", id, ir);
     return id;
-}
-int rt_mat_diffuse_light(rt_builder* b, int tex, double k) {
+} RT_ABI_CATCH
+int rt_mat_diffuse_light(rt_builder* b, int tex, double k) try {
     if (!b) return RT_ERR_INVALID;
     if (!b->valid_tex(tex)) return b->fail(RT_ERR_INVALID, "diffuse_light: bad texture handle %d", tex);
     int id = add_mat(b, RT_MAT_DIFFUSE_LIGHT, tex, k, 0, 0, 0);
     log_fmt(b->log, "mat_diffuse_light %d %d %a\n", id, tex, k);
     return id;
-}
-int rt_mat_isotropic(rt_builder* b, int tex) {
+} RT_ABI_CATCH
+int rt_mat_isotropic(rt_builder* b, int tex) try {
     if (!b) return RT_ERR_INVALID;
     if (!b->valid_tex(tex)) return b->fail(RT_ERR_INVALID, "isotropic: bad texture handle %d", tex);
     int id = add_mat(b, RT_MAT_ISOTROPIC, tex, 0, 0, 0, 0);
     log_fmt(b->log, "mat_isotropic %d %d\n", id, tex);
     return id;
-}
+} RT_ABI_CATCH
 
-int rt_sphere(rt_builder* b, const double c[3], double radius, int mat) {
+int rt_sphere(rt_builder* b, const double c[3], double radius, int mat) try {
     if (!b) return RT_ERR_INVALID;
     if (!c || !b->valid_mat(mat)) return b->fail(RT_ERR_INVALID, "sphere: bad argument");
     ObjRec o; o.kind = OBJ_SPHERE; o.mat = mat; o.d[0] = c[0]; o.d[1] = c[1]; o.d[2] = c[2]; o.d[3] = radius;
     int id = b->add_obj(o);
     log_fmt(b->log, "sphere %d %a %a %a %a %d\n", id, c[0], c[1], c[2], radius, mat);
     return id;
-}
+} RT_ABI_CATCH
 int rt_moving_sphere(rt_builder* b, const double c0[3], const double c1[3], double time0, double time1, double radius,
-                     int mat) {
+                     int mat) try {
     if (!b) return RT_ERR_INVALID;
     if (!c0 || !c1 || !b->valid_mat(mat)) return b->fail(RT_ERR_INVALID, "moving_sphere: bad argument");
     ObjRec o; o.kind = OBJ_MSPHERE; o.mat = mat;
@@ -1354,7 +1356,7 @@ int rt_moving_sphere(rt_builder* b, const double c0[3], const double c1[3], doub
     log_fmt(b->log, "moving_sphere %d %a %a %a %a %a %a %a %a %a %d\n", id, c0[0], c0[1], c0[2], c1[0], c1[1], c1[2],
                time0, time1, radius, mat);
     return id;
-}
+} RT_ABI_CATCH
 static int add_rect(rt_builder* b, ObjKind kind, const char* name, double a0, double a1, double b0, double b1, double k,
                     int mat) {
     if (!b) return RT_ERR_INVALID;
@@ -1364,16 +1366,16 @@ static int add_rect(rt_builder* b, ObjKind kind, const char* name, double a0, do
     log_fmt(b->log, "%s %d %a %a %a %a %a %d\n", name, id, a0, a1, b0, b1, k, mat);
     return id;
 }
-int rt_xy_rect(rt_builder* b, double x0, double x1, double y0, double y1, double k, int mat) {
+int rt_xy_rect(rt_builder* b, double x0, double x1, double y0, double y1, double k, int mat) try {
     return add_rect(b, OBJ_XYRECT, "xy_rect", x0, x1, y0, y1, k, mat);
-}
-int rt_xz_rect(rt_builder* b, double x0, double x1, double z0, double z1, double k, int mat) {
+} RT_ABI_CATCH
+int rt_xz_rect(rt_builder* b, double x0, double x1, double z0, double z1, double k, int mat) try {
     return add_rect(b, OBJ_XZRECT, "xz_rect", x0, x1, z0, z1, k, mat);
-}
-int rt_yz_rect(rt_builder* b, double y0, double y1, double z0, double z1, double k, int mat) {
+} RT_ABI_CATCH
+int rt_yz_rect(rt_builder* b, double y0, double y1, double z0, double z1, double k, int mat) try {
     return add_rect(b, OBJ_YZRECT, "yz_rect", y0, y1, z0, z1, k, mat);
-}
-int rt_box(rt_builder* b, const double p0[3], const double p1[3], int mat) {
+} RT_ABI_CATCH
+int rt_box(rt_builder* b, const double p0[3], const double p1[3], int mat) try {
     if (!b) return RT_ERR_INVALID;
     if (!p0 || !p1 || !b->valid_mat(mat)) return b->fail(RT_ERR_INVALID, "box: bad argument");
     ObjRec o; o.kind = OBJ_BOX; o.mat = mat;
@@ -1381,8 +1383,8 @@ int rt_box(rt_builder* b, const double p0[3], const double p1[3], int mat) {
     int id = b->add_obj(o);
     log_fmt(b->log, "box %d %a %a %a %a %a %a %d\n", id, p0[0], p0[1], p0[2], p1[0], p1[1], p1[2], mat);
     return id;
-}
-int rt_translate(rt_builder* b, int child, const double off[3]) {
+} RT_ABI_CATCH
+int rt_translate(rt_builder* b, int child, const double off[3]) try {
     if (!b) return RT_ERR_INVALID;
     if (!off || !b->valid_obj(child)) return b->fail(RT_ERR_INVALID, "translate: bad argument");
     ObjRec o; o.kind = OBJ_TRANSLATE; o.child = child; o.d[0] = off[0]; o.d[1] = off[1]; o.d[2] = off[2];
@@ -1390,8 +1392,8 @@ int rt_translate(rt_builder* b, int child, const double off[3]) {
     int id = b->add_obj(o);
     log_fmt(b->log, "translate %d %d %a %a %a\n", id, child, off[0], off[1], off[2]);
     return id;
-}
-int rt_rotate_y(rt_builder* b, int child, double angle) {
+} RT_ABI_CATCH
+int rt_rotate_y(rt_builder* b, int child, double angle) try {
     if (!b) return RT_ERR_INVALID;
     if (!b->valid_obj(child)) return b->fail(RT_ERR_INVALID, "rotate_y: bad child handle %d", child);
     ObjRec o; o.kind = OBJ_ROTATE_Y; o.child = child;
@@ -1420,8 +1422,8 @@ int rt_rotate_y(rt_builder* b, int child, double angle) {
     int id = b->add_obj(o);
     log_fmt(b->log, "rotate_y %d %d %a\n", id, child, angle);
     return id;
-}
-int rt_constant_medium(rt_builder* b, int boundary, double density, double r, double g, double bl) {
+} RT_ABI_CATCH
+int rt_constant_medium(rt_builder* b, int boundary, double density, double r, double g, double bl) try {
     if (!b) return RT_ERR_INVALID;
     if (!b->valid_obj(boundary)) return b->fail(RT_ERR_INVALID, "constant_medium: bad boundary handle %d", boundary);
     // ConstantMedium::new_by_color (constant_medium.rs:15-21): phase function = Isotropic(SolidColor(c))
@@ -1434,24 +1436,24 @@ int rt_constant_medium(rt_builder* b, int boundary, double density, double r, do
     int id = b->add_obj(o);
     log_fmt(b->log, "constant_medium %d %d %a %a %a %a %d %d\n", id, boundary, density, r, g, bl, mat, (int)b->texs.size() - 1);
     return id;
-}
-int rt_list_new(rt_builder* b) {
+} RT_ABI_CATCH
+int rt_list_new(rt_builder* b) try {
     if (!b) return RT_ERR_INVALID;
     ObjRec o; o.kind = OBJ_LIST;
     o.exact_bounds = false;
     int id = b->add_obj(o);
     log_fmt(b->log, "list %d\n", id);
     return id;
-}
-int rt_list_add(rt_builder* b, int list, int child) {
+} RT_ABI_CATCH
+int rt_list_add(rt_builder* b, int list, int child) try {
     if (!b) return RT_ERR_INVALID;
     if (!b->valid_obj(list) || b->objs[list].kind != OBJ_LIST || !b->valid_obj(child) || child == list)
         return b->fail(RT_ERR_INVALID, "list_add: bad handle");
     b->objs[list].members.push_back(child);
     log_fmt(b->log, "list_add %d %d\n", list, child);
     return RT_OK;
-}
-int rt_bvh(rt_builder* b, int list, double t0, double t1) {
+} RT_ABI_CATCH
+int rt_bvh(rt_builder* b, int list, double t0, double t1) try {
     if (!b) return RT_ERR_INVALID;
     if (!b->valid_obj(list) || b->objs[list].kind != OBJ_LIST) return b->fail(RT_ERR_INVALID, "bvh: %d is not a list", list);
     if (b->objs[list].members.empty()) return b->fail(RT_ERR_PANIC, "bvh: empty list (bvh.rs:34 would index out of bounds)");
@@ -1496,14 +1498,14 @@ int rt_bvh(rt_builder* b, int list, double t0, double t1) {
     log_raw(b->log, b->axis_log.data(), b->axis_log.size());
     log_fmt(b->log, "\n");
     return id;
-}
+} RT_ABI_CATCH
 
-int rt_builder_compile(rt_builder* b, int world, void** blob, size_t* nbytes) {
+int rt_builder_compile(rt_builder* b, int world, void** blob, size_t* nbytes) try {
     if (!b) return RT_ERR_INVALID;
     b->error.clear();
     return b->compile(world, blob, nbytes);
-}
-int rt_builder_describe(rt_builder* b, int world, char** text, size_t* nbytes) {
+} RT_ABI_CATCH
+int rt_builder_describe(rt_builder* b, int world, char** text, size_t* nbytes) try {
     if (!b) return RT_ERR_INVALID;
     if (!text || !nbytes || !b->valid_obj(world)) return b->fail(RT_ERR_INVALID, "describe: bad argument");
     std::string s = log_text(b->log);
@@ -1515,14 +1517,14 @@ int rt_builder_describe(rt_builder* b, int world, char** text, size_t* nbytes) {
     *text = out;
     *nbytes = s.size();
     return RT_OK;
-}
-int rt_builder_register_image(rt_builder* b, const char* filename, const uint8_t* rgb8, uint32_t width, uint32_t height) {
+} RT_ABI_CATCH
+int rt_builder_register_image(rt_builder* b, const char* filename, const uint8_t* rgb8, uint32_t width, uint32_t height) try {
     if (!b) return RT_ERR_INVALID;
     if (!filename || !rgb8 || !width || !height) return b->fail(RT_ERR_INVALID, "register_image: bad argument");
     rt_builder::Image im; im.width = width; im.height = height;
     im.rgb.assign(rgb8, rgb8 + (size_t)width * height * 3);
     b->images[filename] = std::move(im);
     return RT_OK;
-}
+} RT_ABI_CATCH
 
 } // extern "C"

@@ -3,7 +3,7 @@
 // One render pass traces S camera samples of every pixel this context owns as P = pixels * S paths that
 // advance in lock step, one bounce per iteration:
 //
-//   k_raygen                 slot = local_pixel * S + s  ->  primary ray, throughput 1, radiance 0
+//   k_raygen                 slot = local_pixel * S + s  ->  primary ray (record `slot` of bounce 0's ray array)
 //   per bounce it = 0 .. max_depth-1
 //     k_extend_tree          closest hit of every live path: persistent waves, one 1024-thread workgroup per CU,
 //                            per-lane stacks and the top of the node array in LDS
@@ -14,7 +14,10 @@
 //     k_shade<bucket>        the same shading for one queue of computed-texture hits
 //   k_accumulate             per pixel, add its S sample radiances in sample order to the f64 sum buffer
 //
-// Path state is one 64-byte record per path and array (ray; throughput + radiance) plus a 16-byte hit record.
+// Path state per bounce is dense: a 64-byte ray record (with the path's slot and pixel), a 24-byte throughput record
+// (none at the first bounce, where it is 1) and a 16-byte hit record per live path, double-buffered. The radiance array
+// (3 doubles per slot) is written exactly once per path, by the kernel in which the path ends - every path ends
+// (miss, absorption, light, or the last bounce), so no slot keeps a value from an earlier pass.
 // All queue lengths live in a device counter table that the kernels read themselves, so the host never waits
 // between launches inside a pass. Random numbers are Philox keyed on (pixel, sample, bounce): results do not
 // depend on how pixels are split over GPUs or on scheduling.
@@ -33,7 +36,11 @@
 #include "rt_device.h"
 #include "rt_tree_build.h"
 
+// Nothing may unwind across the C ABI: the entry points are function-try-blocks that end in this.
+#define RT_ABI_CATCH catch (const std::bad_alloc&) { return RT_ERR_OOM; } catch (...) { return RT_ERR_INVALID; }
+
 #define RT_BLOCK 256
+static_assert(RT_BLOCK % 64 == 0, "kernels hand data from lane to lane inside 64-lane waves");
 #define RT_TREE_BLOCK 1024 /* k_extend_tree: one workgroup per CU, so that the whole CU shares one LDS copy of the top of the tree */
 #define RT_COUNTER_STRIDE 16u /* per iteration: [0] paths entering it at the front of the arrays, [1+q] hits in queue q, [RT_COUNTER_BACK] paths entering it at the back */
 #define RT_COUNTER_BACK 15u
@@ -107,6 +114,11 @@ struct LdsStack {
 // lanes of one read spread over all banks.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u32x4* LdsU4; // typed as LDS so that reads are ds_read, not flat loads
+// ALL = true: every node of the scene is in LDS. The kernel is then compiled without the global-memory branch, and that
+// matters beyond the branch: where both branches exist they write the same registers, so the compiler has to make the LDS
+// reads wait for every outstanding vector-memory operation of the wave (s_waitcnt vmcnt(0): on gfx9 that counts stores
+// too) - each box step then waits for the hit record a lane has just published and for any leaf record on its way.
+template <bool ALL>
 struct CachedNodes {
     LdsU4 lds;
     uint32_t n_cached;
@@ -114,7 +126,7 @@ struct CachedNodes {
     __device__ static uint32_t place(uint32_t index, uint32_t piece) { return index * 4u + (piece ^ ((index >> 2) & 3u)); }
     __device__ RtNode load(uint32_t index) const {
         u32x4 a, b, c, d; // (d as a full 16-byte read too: a narrower one gets merged with the other branch's into a flat load)
-        if (index < n_cached) {
+        if (ALL || index < n_cached) {
             a = lds[place(index, 0u)]; b = lds[place(index, 1u)]; c = lds[place(index, 2u)]; d = lds[place(index, 3u)];
         } else {
             const u32x4* g = (const u32x4*)(global + index);
@@ -260,6 +272,11 @@ __device__ double PhiloxXi<ONLY_SPHERE_MEDIA>::operator()(uint32_t medium_index)
 }
 
 // ---- kernels ------------------------------------------------------------------------------------------------
+// k_raygen, k_accumulate and k_extend_tree exchange data between the lanes of a wave (ballots over 64 lanes, LDS staging
+// indexed by threadIdx.x >> 6 with wavefront-scope fences): they are written for gfx950's 64-lane waves only.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__AMDGCN_WAVEFRONT_SIZE) && __AMDGCN_WAVEFRONT_SIZE != 64
+#error "rt_kernels.hip assumes 64-lane wavefronts"
+#endif
 __global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtCameraDev cam, PassInfo pi, PathBufs pb) {
     __shared__ double2 stage[RT_BLOCK * 4];
     const uint32_t n = pi.n_local * pi.S;
@@ -313,14 +330,18 @@ __global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtCameraDev cam, PassInfo p
 // Debug build only: how the waves of k_extend_tree spend their iterations, by bounce (0, 1, 2, 3+).
 __device__ unsigned long long g_phase[4][48];
 #define RT_PHASE_ADD(k, v) (ph[k] += (v))
+#define RT_PHASE_CLOCK(var) const long long var = clock64()
+#define RT_PHASE_SPAN(k, a, b) (ph[k] += (unsigned long long)((b) - (a)))
 #else
 #define RT_PHASE_ADD(k, v) ((void)0)
+#define RT_PHASE_CLOCK(var) ((void)0)
+#define RT_PHASE_SPAN(k, a, b) ((void)0)
 #endif
 // EXACT_NODES = false: the scene has no node whose box tests must reproduce the reference's f64 arithmetic.
 // SPHERE_MEDIA = true: every ConstantMedium of the scene is bounded by a plain sphere.
 // QUERY = true: the rays are a caller's batch (`qb`) instead of the live paths of bounce `it`: same scheduling, same
 // node cache, same leaf rounds; per-ray t_min / t_max and injected medium uniforms.
-template <bool EXACT_NODES, bool SPHERE_MEDIA, bool QUERY>
+template <bool EXACT_NODES, bool SPHERE_MEDIA, bool QUERY, bool ALL_CACHED>
 __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
                                                                uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_min,
                                                                uint32_t n_cached, QueryBatch qb) {
@@ -349,11 +370,11 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
     st.stride = blockDim.x;
     st.error_flag = qs.error_flag;
     st.sp = 0u;
-    CachedNodes nodes;
+    CachedNodes<ALL_CACHED> nodes;
     {
         uint4* cache = lds_tree + (size_t)stack_cap * blockDim.x / 4u;
         const uint4* src = (const uint4*)sc.nodes;
-        for (uint32_t i = threadIdx.x; i < n_cached * 4u; i += blockDim.x) cache[CachedNodes::place(i >> 2, i & 3u)] = src[i];
+        for (uint32_t i = threadIdx.x; i < n_cached * 4u; i += blockDim.x) cache[CachedNodes<ALL_CACHED>::place(i >> 2, i & 3u)] = src[i];
         nodes.lds = (LdsU4)cache;
         nodes.n_cached = n_cached;
         nodes.global = sc.nodes;
@@ -386,6 +407,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
         if (n_idle == 64u && exhausted) break;
         RT_PHASE_ADD(0, 1); RT_PHASE_ADD(7, 64u - n_idle);
         if (n_idle >= refill_min && !exhausted) { // hand idle lanes the next rays
+            RT_PHASE_CLOCK(c_round1);
             uint32_t v0 = 0u;
             if (lane == 0u) v0 = atomicAdd(&blk_taken, n_idle);
             v0 = __shfl(v0, 0);
@@ -414,8 +436,11 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
                 }
             }
             if (index_of(v0 + n_idle) >= n) exhausted = true; // whoever draws next would find nothing
+            RT_PHASE_CLOCK(c_round2);
+            RT_PHASE_SPAN(41, c_round1, c_round2);
             if (__ballot(active) == 0ull && exhausted) break;
         }
+        RT_PHASE_CLOCK(c_nodes0);
         // ---- box tests: every lane that holds a node steps ----
 #pragma unroll 1
         for (;;) {
@@ -428,6 +453,8 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             // time; a third and fourth step bring nothing more)
             if (active && RT_REF_TYPE(s.cur) == RT_REF_NODE) rt_trav_node_step<EXACT_NODES>(nodes, s, st, t_min);
         }
+        RT_PHASE_CLOCK(c_nodes1);
+        RT_PHASE_SPAN(42, c_nodes0, c_nodes1);
         // ---- one non-node reference for every lane that holds one ----
 #ifdef RT_PHASE_STATS
         {
@@ -457,6 +484,8 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             (QUERY ? qb.hit : pb.hit)[path] = h;
             active = false;
         }
+        RT_PHASE_CLOCK(c_leaf1);
+        RT_PHASE_SPAN(43, c_nodes1, c_leaf1);
     }
 #ifdef RT_PHASE_STATS
     if (lane == 0u)
@@ -760,7 +789,7 @@ struct rt_context {
     size_t pm_cap = 0;
     std::vector<hipEvent_t> events;
     // k_extend thresholds (lanes of a wave): refill once this many lanes are out of work, test leaves once this many wait
-    uint32_t tune_refill = 0, tune_leaf = 0; // 0 = the defaults of rt_render_accumulate; RT_TUNE_REFILL / RT_TUNE_LEAF override
+    uint32_t tune_refill = 0, tune_leaf = 0; // 0 = the defaults of extend_launch_of; RT_TUNE_REFILL / RT_TUNE_LEAF override
 };
 
 namespace {
@@ -939,10 +968,11 @@ int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t f
     // earlier refills and leaf rounds than trees that replay the reference's order (long forced descents).
     out->refill_min = ctx->tune_refill ? ctx->tune_refill : (exact_nodes ? 44u : 36u);
     out->leaf_min = ctx->tune_leaf ? ctx->tune_leaf : (exact_nodes ? 36u : 30u);
-    static const ExtendKernel table[2][2][2] = {
-        {{k_extend_tree<false, false, false>, k_extend_tree<false, false, true>}, {k_extend_tree<false, true, false>, k_extend_tree<false, true, true>}},
-        {{k_extend_tree<true, false, false>, k_extend_tree<true, false, true>}, {k_extend_tree<true, true, false>, k_extend_tree<true, true, true>}}};
-    out->kernel = table[exact_nodes][sphere_media][query];
+#define RT_EXT_ROW(E, S) {{k_extend_tree<E, S, false, false>, k_extend_tree<E, S, false, true>}, {k_extend_tree<E, S, true, false>, k_extend_tree<E, S, true, true>}}
+    static const ExtendKernel table[2][2][2][2] = {{RT_EXT_ROW(false, false), RT_EXT_ROW(false, true)}, {RT_EXT_ROW(true, false), RT_EXT_ROW(true, true)}};
+#undef RT_EXT_ROW
+    const bool all_cached = n_cached == sc->hdr.nodes.count && !getenv("RT_AB_NOT_ALL_CACHED");
+    out->kernel = table[exact_nodes][sphere_media][query][all_cached];
     if (lds > 65536)
         RT_HIP(hipFuncSetAttribute((const void*)out->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size of k_extend_tree");
     if (getenv("RT_DEBUG"))
@@ -965,7 +995,7 @@ void launch_shade(rt_context* ctx, const rt_scene* sc, const PassInfo& pi, const
 
 extern "C" {
 
-int rt_init(rt_context** out, int device) {
+int rt_init(rt_context** out, int device) try {
     if (!out) return RT_ERR_INVALID;
     *out = nullptr;
     int n = 0;
@@ -989,7 +1019,13 @@ int rt_init(rt_context** out, int device) {
         delete ctx;
         return RT_ERR_OOM;
     }
-    hipMemset(ctx->error_flag, 0, sizeof(uint32_t));
+    if (hipMemsetAsync(ctx->error_flag, 0, sizeof(uint32_t), ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        hipFree(ctx->error_flag);
+        hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return RT_ERR_NO_DEVICE;
+    }
     {   // this device's address of the scratch array (the device is current: hipSetDevice above)
         void* p = nullptr;
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) {
@@ -1005,7 +1041,7 @@ int rt_init(rt_context** out, int device) {
     if (const char* e = getenv("RT_TUNE_LEAF")) ctx->tune_leaf = (uint32_t)std::max(1, std::min(64, atoi(e)));
     *out = ctx;
     return RT_OK;
-}
+} RT_ABI_CATCH
 
 void rt_shutdown(rt_context* ctx) {
     if (!ctx) return;
@@ -1024,7 +1060,7 @@ void rt_shutdown(rt_context* ctx) {
 
 const char* rt_last_error(const rt_context* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
 
-static int upload_common(rt_context* ctx, const void* src, size_t nbytes, bool src_on_device, rt_scene** out) {
+static int upload_common(rt_context* ctx, const void* src, size_t nbytes, bool src_on_device, rt_scene** out) try {
     if (!ctx) return RT_ERR_INVALID;
     if (!src || !out || nbytes < sizeof(RtBlobHeader)) return ctx_fail(ctx, RT_ERR_INVALID, "scene_upload: bad argument");
     RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
@@ -1067,9 +1103,9 @@ static int upload_common(rt_context* ctx, const void* src, size_t nbytes, bool s
     }
     *out = s;
     return RT_OK;
-}
-int rt_scene_upload(rt_context* ctx, const void* blob, size_t nbytes, rt_scene** out) { return upload_common(ctx, blob, nbytes, false, out); }
-int rt_scene_upload_from_device(rt_context* ctx, const void* d_blob, size_t nbytes, rt_scene** out) { return upload_common(ctx, d_blob, nbytes, true, out); }
+} RT_ABI_CATCH
+int rt_scene_upload(rt_context* ctx, const void* blob, size_t nbytes, rt_scene** out) try { return upload_common(ctx, blob, nbytes, false, out); } RT_ABI_CATCH
+int rt_scene_upload_from_device(rt_context* ctx, const void* d_blob, size_t nbytes, rt_scene** out) try { return upload_common(ctx, d_blob, nbytes, true, out); } RT_ABI_CATCH
 void rt_scene_free(rt_context* ctx, rt_scene* s) {
     if (!s) return;
     if (ctx) hipSetDevice(ctx->device);
@@ -1077,7 +1113,7 @@ void rt_scene_free(rt_context* ctx, rt_scene* s) {
     delete s;
 }
 
-int rt_scene_build_tree_device(rt_context* ctx, rt_scene* sc, rt_tree_stats* stats) {
+int rt_scene_build_tree_device(rt_context* ctx, rt_scene* sc, rt_tree_stats* stats) try {
     if (!ctx) return RT_ERR_INVALID;
     if (!sc) return ctx_fail(ctx, RT_ERR_INVALID, "build_tree_device: null scene");
     if (stats) memset(stats, 0, sizeof *stats);
@@ -1107,19 +1143,19 @@ int rt_scene_build_tree_device(rt_context* ctx, rt_scene* sc, rt_tree_stats* sta
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     return RT_OK;
-}
+} RT_ABI_CATCH
 
 static int check_error_flag(rt_context* ctx) {
     uint32_t flag = 0;
     RT_HIP(hipMemcpy(&flag, ctx->error_flag, sizeof flag, hipMemcpyDeviceToHost), "read error flag");
     if (flag) {
-        hipMemset(ctx->error_flag, 0, sizeof(uint32_t));
+        hipMemsetAsync(ctx->error_flag, 0, sizeof(uint32_t), ctx->stream); // (the stream the kernels that raise it run on)
         return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "traversal stack overflow on device");
     }
     return RT_OK;
 }
 
-int rt_trace_first_hit(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays, size_t n, const double* medium_xi, rt_hit* out) {
+int rt_trace_first_hit(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays, size_t n, const double* medium_xi, rt_hit* out) try {
     if (!ctx) return RT_ERR_INVALID;
     if (!sc || (!rays && n) || (!out && n) || n > 0x7FFFFFFFu) return ctx_fail(ctx, RT_ERR_INVALID, "trace_first_hit: bad argument");
     if (n == 0) return RT_OK;
@@ -1152,10 +1188,10 @@ int rt_trace_first_hit(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays
     if (d_xi) hipFree(d_xi);
     if (rc == RT_OK) rc = check_error_flag(ctx);
     return rc;
-}
+} RT_ABI_CATCH
 
 int rt_trace_first_hit_wavefront(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays, size_t n, const double* medium_xi,
-                                 rt_hit* out, uint32_t variant) {
+                                 rt_hit* out, uint32_t variant) try {
     if (!ctx) return RT_ERR_INVALID;
     if (!sc || (!rays && n) || (!out && n) || n > 0x7FFFFFFFu || variant > 3u) return ctx_fail(ctx, RT_ERR_INVALID, "trace_first_hit_wavefront: bad argument");
     if (n == 0) return RT_OK;
@@ -1202,9 +1238,9 @@ int rt_trace_first_hit_wavefront(rt_context* ctx, const rt_scene* sc, const rt_r
     if (d_xi) hipFree(d_xi);
     if (rc == RT_OK) rc = check_error_flag(ctx);
     return rc;
-}
+} RT_ABI_CATCH
 
-int rt_trace_first_hit_noalloc(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays, size_t n, const double* medium_xi, rt_hit* out) {
+int rt_trace_first_hit_noalloc(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays, size_t n, const double* medium_xi, rt_hit* out) try {
     if (!ctx) return RT_ERR_INVALID;
     if (!sc || (!rays && n) || (!out && n)) return ctx_fail(ctx, RT_ERR_INVALID, "trace_first_hit_noalloc: bad argument");
     if (n == 0) return RT_OK;
@@ -1245,9 +1281,9 @@ int rt_trace_first_hit_noalloc(rt_context* ctx, const rt_scene* sc, const rt_ray
     if (e != hipSuccess) { (void)hipGetLastError(); return ctx_fail(ctx, RT_ERR_NO_DEVICE, "trace_first_hit_noalloc", e); }
     if (flag) return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "traversal stack overflow on device");
     return RT_OK;
-}
+} RT_ABI_CATCH
 
-int rt_generate_rays(rt_context* ctx, const rt_camera* cam, const rt_params* p, uint32_t sample, rt_ray_d* out) {
+int rt_generate_rays(rt_context* ctx, const rt_camera* cam, const rt_params* p, uint32_t sample, rt_ray_d* out) try {
     if (!ctx) return RT_ERR_INVALID;
     if (!cam || !p || !out || p->width < 2 || p->height < 2) return ctx_fail(ctx, RT_ERR_INVALID, "generate_rays: bad argument");
     RtCameraDev cd;
@@ -1264,10 +1300,10 @@ int rt_generate_rays(rt_context* ctx, const rt_camera* cam, const rt_params* p, 
     hipFree(d);
     if (e != hipSuccess) return ctx_fail(ctx, RT_ERR_NO_DEVICE, "generate_rays", e);
     return RT_OK;
-}
+} RT_ABI_CATCH
 
 int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, uint32_t sample_offset,
-                         uint32_t spp, double* d_rgb_sum, rt_stats* stats) {
+                         uint32_t spp, double* d_rgb_sum, rt_stats* stats) try {
     if (!ctx) return RT_ERR_INVALID;
     if (!sc || !cam || !p || !d_rgb_sum) return ctx_fail(ctx, RT_ERR_INVALID, "render: null argument");
     if (p->width < 2 || p->height < 2 || p->max_depth == 0 || p->max_depth > 65535u)
@@ -1401,7 +1437,7 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
     }
     if (stats) stats->seconds_render += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     return check_error_flag(ctx);
-}
+} RT_ABI_CATCH
 
 void rt_tonemap(const double* rgb_sum, size_t n_pixels, double spp, uint8_t* rgb8_out) {
     if (!rgb_sum || !rgb8_out) return;
@@ -1409,14 +1445,14 @@ void rt_tonemap(const double* rgb_sum, size_t n_pixels, double spp, uint8_t* rgb
 }
 
 int rt_render(rt_context* ctx, const rt_scene* sc, const rt_camera* cam, const rt_params* p, uint32_t spp, double* rgb_sum_out,
-              uint8_t* rgb8_out, rt_stats* stats) {
+              uint8_t* rgb8_out, rt_stats* stats) try {
     if (!ctx) return RT_ERR_INVALID;
     if (!p || !rgb_sum_out) return ctx_fail(ctx, RT_ERR_INVALID, "render: null argument");
     RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     const size_t n = (size_t)p->width * p->height * 3;
     double* d_sum = nullptr;
     RT_HIP(hipMalloc((void**)&d_sum, n * sizeof(double)), "hipMalloc framebuffer");
-    hipError_t e = hipMemset(d_sum, 0, n * sizeof(double));
+    hipError_t e = hipMemsetAsync(d_sum, 0, n * sizeof(double), ctx->stream); // ordered before the render's kernels: same stream
     int rc = e == hipSuccess ? rt_render_accumulate(ctx, sc, cam, p, 0, spp, d_sum, stats) : ctx_fail(ctx, RT_ERR_NO_DEVICE, "memset", e);
     if (rc == RT_OK) {
         e = hipMemcpy(rgb_sum_out, d_sum, n * sizeof(double), hipMemcpyDeviceToHost);
@@ -1425,38 +1461,39 @@ int rt_render(rt_context* ctx, const rt_scene* sc, const rt_camera* cam, const r
     hipFree(d_sum);
     if (rc == RT_OK && rgb8_out) rt_tonemap(rgb_sum_out, (size_t)p->width * p->height, (double)spp, rgb8_out);
     return rc;
-}
+} RT_ABI_CATCH
 
-int rt_device_alloc(rt_context* ctx, size_t nbytes, void** d_ptr) {
+int rt_device_alloc(rt_context* ctx, size_t nbytes, void** d_ptr) try {
     if (!ctx) return RT_ERR_INVALID;
     if (!d_ptr) return ctx_fail(ctx, RT_ERR_INVALID, "device_alloc: null argument");
     RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     RT_HIP(hipMalloc(d_ptr, nbytes), "hipMalloc");
     return RT_OK;
-}
-int rt_device_free(rt_context* ctx, void* d_ptr) {
+} RT_ABI_CATCH
+int rt_device_free(rt_context* ctx, void* d_ptr) try {
     if (!ctx) return RT_ERR_INVALID;
     RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     RT_HIP(hipFree(d_ptr), "hipFree");
     return RT_OK;
-}
-int rt_device_memset(rt_context* ctx, void* d_ptr, int value, size_t nbytes) {
+} RT_ABI_CATCH
+int rt_device_memset(rt_context* ctx, void* d_ptr, int value, size_t nbytes) try {
     if (!ctx) return RT_ERR_INVALID;
     RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
-    RT_HIP(hipMemset(d_ptr, value, nbytes), "hipMemset");
+    RT_HIP(hipMemsetAsync(d_ptr, value, nbytes, ctx->stream), "hipMemset"); // on the stream the kernels run on, and finished on return
+    RT_HIP(hipStreamSynchronize(ctx->stream), "hipMemset");
     return RT_OK;
-}
-int rt_device_download(rt_context* ctx, void* host_dst, const void* d_src, size_t nbytes) {
+} RT_ABI_CATCH
+int rt_device_download(rt_context* ctx, void* host_dst, const void* d_src, size_t nbytes) try {
     if (!ctx) return RT_ERR_INVALID;
     RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     RT_HIP(hipMemcpy(host_dst, d_src, nbytes, hipMemcpyDeviceToHost), "hipMemcpy");
     return RT_OK;
-}
-int rt_device_upload(rt_context* ctx, void* d_dst, const void* host_src, size_t nbytes) {
+} RT_ABI_CATCH
+int rt_device_upload(rt_context* ctx, void* d_dst, const void* host_src, size_t nbytes) try {
     if (!ctx) return RT_ERR_INVALID;
     RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
     RT_HIP(hipMemcpy(d_dst, host_src, nbytes, hipMemcpyHostToDevice), "hipMemcpy");
     return RT_OK;
-}
+} RT_ABI_CATCH
 
 } // extern "C"
