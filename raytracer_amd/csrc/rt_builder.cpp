@@ -1116,7 +1116,10 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     const size_t biggest = std::max({f.nodes.size(), f.spheres.size(), f.mspheres.size(), f.rects.size(), f.boxes.size(), f.media.size(),
                                      f.insts.size(), f.list_entries.size()});
     if (biggest > (size_t)RT_REF_INDEX_MASK) return fail(RT_ERR_UNSUPPORTED, "scene too large: %zu records of one kind, limit %u", biggest, RT_REF_INDEX_MASK);
-    const uint32_t stack_need = std::max(1u, need) + 1u;
+    // `need` is exact: a node whose two boxes are both hit pushes one entry, nothing else does, so the deepest chain of
+    // nodes is the most the stack ever holds. No spare entry: the traversal kernel's stacks and its copy of the top of the
+    // tree share 160 KB of LDS, and for the Book-2 scene one entry less (4 KB) is what lets the whole tree in.
+    const uint32_t stack_need = std::max(1u, need);
     if (stack_need > RT_STACK_CAP)
         return fail(RT_ERR_UNSUPPORTED, "scene needs a traversal stack of %u entries, capacity is %u", stack_need, RT_STACK_CAP);
 

@@ -1134,7 +1134,7 @@ int rt_scene_build_tree_device(rt_context* ctx, rt_scene* sc, rt_tree_stats* sta
     sc->tree_built = true;
     if (h.device_tree_leaves >= 2u) {
         const uint32_t need = std::max(h.device_tree_need_other, res.height + h.device_tree_leaf_need) + h.device_tree_need_add;
-        sc->hdr.stack_need = std::max(1u, need) + 1u;
+        sc->hdr.stack_need = std::max(1u, need);
     }
     if (stats) {
         stats->leaves = h.device_tree_leaves; stats->height = res.height; stats->key_bits = res.key_bits; stats->stack_need = sc->hdr.stack_need;

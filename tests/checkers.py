@@ -129,6 +129,9 @@ def hostsim_trace_first_hit(blob, rays, medium_xi=None, compat=0):
                                       compat, out.ctypes.data, C.byref(high))
     if rc != 0:
         raise RuntimeError("hostsim trace failed: %d" % rc)
+    import struct
+    need = struct.unpack_from("<I", blob, 32)[0]
+    assert high.value <= need, "traversal used %d stack entries, the blob's header asks for %d" % (high.value, need)
     return out, high.value
 
 
