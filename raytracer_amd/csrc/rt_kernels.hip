@@ -323,8 +323,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_raygen(RtCameraDev cam, PassInfo p
 //    (piece c belongs to workgroup c mod gridDim) and the waves of a workgroup draw from its pieces through a
 //    counter in LDS: a counter in global memory takes ~90 atomics per microsecond chip-wide, which at one
 //    atomic per 64 rays would cap the kernel at 6 G rays/s and dominate small launches;
-//  * box tests run for all lanes that hold a node until `leaf_min` lanes wait at a leaf; then those
-//    leaves are tested together.
+//  * box tests run for all lanes that hold a node until `leaf_pct` per cent of the lanes that hold a ray wait at a
+//    leaf; then those leaves are tested together.
 // Which lane traces which ray, and when, has no effect on results.
 #ifdef RT_PHASE_STATS
 // Debug build only: how the waves of k_extend_tree spend their iterations, by bounce (0, 1, 2, 3+).
@@ -343,7 +343,7 @@ __device__ unsigned long long g_phase[4][48];
 // node cache, same leaf rounds; per-ray t_min / t_max and injected medium uniforms.
 template <bool EXACT_NODES, bool SPHERE_MEDIA, bool QUERY, bool ALL_CACHED>
 __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
-                                                               uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_min,
+                                                               uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_pct,
                                                                uint32_t n_cached, QueryBatch qb) {
     extern __shared__ uint4 lds_tree[]; // stack_cap * blockDim.x words of stack, n_cached node records, the queue counter
     const PathRay* rays = pb.ray[it & 1u];
@@ -441,12 +441,16 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             if (__ballot(active) == 0ull && exhausted) break;
         }
         RT_PHASE_CLOCK(c_nodes0);
+        // Leaves are tested once this many lanes wait at one: leaf_pct per cent of the lanes that hold a ray at all. (A fixed
+        // number - 30 of 64 - is too many just before a refill, when 30 lanes are most of those left, and the few still
+        // at a node then step alone; in proportion: -3.4 % kernel time on the Book-2 scene, -7 % on cornell_smoke.)
+        const uint32_t leaf_now = max(4u, (uint32_t)__popcll(__ballot(active)) * leaf_pct / 100u);
         // ---- box tests: every lane that holds a node steps ----
 #pragma unroll 1
         for (;;) {
             const bool at_node = active && RT_REF_TYPE(s.cur) == RT_REF_NODE;
             if (__ballot(at_node) == 0ull) break;
-            if ((uint32_t)__popcll(__ballot(active && !at_node)) >= leaf_min) break;
+            if ((uint32_t)__popcll(__ballot(active && !at_node)) >= leaf_now) break;
             RT_PHASE_ADD(3, 1); RT_PHASE_ADD(4, __popcll(__ballot(at_node)));
             if (at_node) rt_trav_node_step<EXACT_NODES>(nodes, s, st, t_min);
             // a second step before the next look at the wave: the two ballots above cost a sixth of a step (-3.6 % kernel
@@ -788,7 +792,7 @@ struct rt_context {
     uint32_t pm_w = 0, pm_h = 0, pm_tile = 0, pm_rank = 0, pm_world = 0, pm_n = 0;
     size_t pm_cap = 0;
     std::vector<hipEvent_t> events;
-    // k_extend thresholds (lanes of a wave): refill once this many lanes are out of work, test leaves once this many wait
+    // k_extend thresholds: refill once this many lanes of a wave are out of work, test leaves once this per cent of its ray-holding lanes wait at one
     uint32_t tune_refill = 0, tune_leaf = 0; // 0 = the defaults of extend_launch_of; RT_TUNE_REFILL / RT_TUNE_LEAF override
 };
 
@@ -950,7 +954,7 @@ typedef void (*ExtendKernel)(DScene, PassInfo, PathBufs, QueueSet, uint32_t, uin
 struct ExtendLaunch {
     ExtendKernel kernel;
     size_t lds;
-    uint32_t stack_cap, n_cached, refill_min, leaf_min;
+    uint32_t stack_cap, n_cached, refill_min, leaf_pct;
 };
 // `force`: bit 0 = the instantiation with exact f64 box tests even if the scene has no node that needs them, bit 1 = the
 // one with the general medium-boundary code even if every medium is bounded by a sphere (both are valid for any scene).
@@ -964,10 +968,11 @@ int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t f
     const size_t lds = lds_stack_bytes + (size_t)n_cached * sizeof(RtNode) + 16;
     const bool exact_nodes = sc->hdr.n_exact_nodes != 0u || (force & 1u);
     const bool sphere_media = sc->sphere_media && !(force & 2u);
-    // Scheduling thresholds of the traversal kernel, from sweeps (tools/tune.sh): trees walked nearest child first like
-    // earlier refills and leaf rounds than trees that replay the reference's order (long forced descents).
-    out->refill_min = ctx->tune_refill ? ctx->tune_refill : (exact_nodes ? 44u : 36u);
-    out->leaf_min = ctx->tune_leaf ? ctx->tune_leaf : (exact_nodes ? 36u : 30u);
+    // Scheduling thresholds of the traversal kernel, from sweeps (tools/tune.sh): idle lanes of a wave before it draws new
+    // rays (trees that replay the reference's order - long forced descents - like later refills), and the share of its
+    // ray-holding lanes that must wait at a leaf before the leaves are tested.
+    out->refill_min = ctx->tune_refill ? ctx->tune_refill : (exact_nodes ? 48u : 42u);
+    out->leaf_pct = ctx->tune_leaf ? ctx->tune_leaf : 80u;
 #define RT_EXT_ROW(E, S) {{k_extend_tree<E, S, false, false>, k_extend_tree<E, S, false, true>}, {k_extend_tree<E, S, true, false>, k_extend_tree<E, S, true, true>}}
     static const ExtendKernel table[2][2][2][2] = {{RT_EXT_ROW(false, false), RT_EXT_ROW(false, true)}, {RT_EXT_ROW(true, false), RT_EXT_ROW(true, true)}};
 #undef RT_EXT_ROW
@@ -1038,7 +1043,7 @@ int rt_init(rt_context** out, int device) try {
         ctx->noalloc = (unsigned char*)p;
     }
     if (const char* e = getenv("RT_TUNE_REFILL")) ctx->tune_refill = (uint32_t)std::max(1, std::min(64, atoi(e)));
-    if (const char* e = getenv("RT_TUNE_LEAF")) ctx->tune_leaf = (uint32_t)std::max(1, std::min(64, atoi(e)));
+    if (const char* e = getenv("RT_TUNE_LEAF")) ctx->tune_leaf = (uint32_t)std::max(1, std::min(100, atoi(e))); // per cent
     *out = ctx;
     return RT_OK;
 } RT_ABI_CATCH
@@ -1225,7 +1230,7 @@ int rt_trace_first_hit_wavefront(rt_context* ctx, const rt_scene* sc, const rt_r
         qs.error_flag = ctx->error_flag;
         const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min<size_t>((n + RT_TREE_BLOCK - 1) / RT_TREE_BLOCK, (size_t)ctx->n_cu));
         hipLaunchKernelGGL(xl.kernel, dim3(grid), dim3(RT_TREE_BLOCK), xl.lds, ctx->stream, sc->view, pi, pb, qs, 0u, xl.stack_cap,
-                           xl.refill_min, xl.leaf_min, xl.n_cached, qb);
+                           xl.refill_min, xl.leaf_pct, xl.n_cached, qb);
         hipLaunchKernelGGL(k_query_finish, dim3(grid_for(ctx, n, 8)), dim3(RT_BLOCK), 0, ctx->stream, sc->view, qb, d_out);
         e = hipGetLastError();
     }
@@ -1348,7 +1353,7 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
     ExtendLaunch xl;
     rc = extend_launch_of(ctx, sc, false, 0u, &xl);
     if (rc != RT_OK) return rc;
-    const uint32_t stack_cap = xl.stack_cap, refill_min = xl.refill_min, leaf_min = xl.leaf_min, n_cached = xl.n_cached;
+    const uint32_t stack_cap = xl.stack_cap, refill_min = xl.refill_min, leaf_pct = xl.leaf_pct, n_cached = xl.n_cached;
     const size_t lds = xl.lds;
     const ExtendKernel k_extend = xl.kernel;
     const uint32_t extend_blocks_per_cu = 1u;
@@ -1381,7 +1386,7 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
         for (uint32_t it = 0; it < p->max_depth; ++it) {
             a = tm.begin();
             hipLaunchKernelGGL(k_extend, dim3(g_ext), dim3(RT_TREE_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it, stack_cap,
-                               refill_min, leaf_min, n_cached, no_query);
+                               refill_min, leaf_pct, n_cached, no_query);
             tm.end(a, 1);
             a = tm.begin();
             hipLaunchKernelGGL(k_shade_main, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);
