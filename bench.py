@@ -111,6 +111,8 @@ def launch_ranks(world):
     """`python bench.py --gpus N` without a launcher: this process starts the N ranks (fresh children; nothing here has
     touched a GPU), lets rank 0's JSON line through and exits with the worst exit code."""
     have = torch.cuda.device_count()  # counts devices without initialising one
+    if "--rehearse-on-one-gpu" in sys.argv:
+        have = world if have >= 1 else 0
     if have < world:
         raise SystemExit("bench.py --gpus %d needs %d GPUs on this machine; it has %d" % (world, world, have))
     from raytracer_amd import dist as rdist
@@ -128,6 +130,9 @@ def main():
     ap.add_argument("--spp", type=int, default=1536, help="samples per pixel per GPU per step (reduced - 1536, 1024, 512, ... - until the path state fits the GPU)")
     ap.add_argument("--scene", default="final_scene")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="every rank renders on cuda:0 and the collectives run over gloo: the N-rank code path (launch, "
+                         "broadcast, tile sharding, gather) on a machine with one GPU; the rates it prints mean nothing")
     args = ap.parse_args()
 
     world = args.gpus
@@ -146,8 +151,12 @@ def main():
         import torch.distributed as dist
         if int(os.environ["WORLD_SIZE"]) != world:
             raise SystemExit("--gpus %d but the launcher started %s ranks" % (world, os.environ["WORLD_SIZE"]))
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         rccl_ranks = dist.get_world_size()
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
@@ -259,7 +268,7 @@ def main():
         out = {
             "metric": "rays_per_sec", "value": segments / elapsed, "unit": "rays/s",
             "samples_per_sec": samples / elapsed,
-            "n_gpus": world, "rccl_ranks": rccl_ranks, "rays_per_sec_per_gpu": rate, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "collectives": "gloo (one-GPU rehearsal)" if args.rehearse_on_one_gpu else "rccl", "rays_per_sec_per_gpu": rate, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s, %dx%d, max depth %d, %d spp per step (%d per GPU), scene seed 0x5EED0001, render seed 0x5EED0002" %
                                    ("Book-2 final scene (final_scene, main.rs:576-688)" if args.scene == "final_scene" else "scene " + args.scene,
