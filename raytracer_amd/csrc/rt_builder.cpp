@@ -325,6 +325,7 @@ struct rt_builder::Flat {
     std::vector<RtMedium> media;
     std::vector<RtInst> insts;
     std::vector<uint32_t> list_entries;
+    std::vector<RtExactBox> exact_boxes; // f64 bounds of the child-0 boxes of RT_NODE_EXACT nodes (RtNode::pad[1])
     uint32_t max_chain = 0;
     uint32_t n_media = 0;
 };
@@ -448,6 +449,14 @@ namespace {
 const float kInfF = std::numeric_limits<float>::infinity();
 void set_box(float (&lo)[3], float (&hi)[3], const AABB& b) {
     for (int i = 0; i < 3; ++i) { lo[i] = round_down_f32(b.lo[i]); hi[i] = round_up_f32(b.hi[i]); }
+}
+// Child 0 of an RT_NODE_EXACT node: the f32 copy in the node (for the kernels that only cull) and the bounds themselves.
+void set_box0_exact(rt_builder::Flat& f, uint32_t node, const AABB& b) {
+    set_box(f.nodes[node].lo0, f.nodes[node].hi0, b);
+    RtExactBox e;
+    for (int i = 0; i < 3; ++i) { e.lo[i] = b.lo[i]; e.hi[i] = b.hi[i]; }
+    f.exact_boxes.push_back(e);
+    f.nodes[node].pad[1] = (uint32_t)f.exact_boxes.size();
 }
 void set_box_empty(float (&lo)[3], float (&hi)[3]) { for (int i = 0; i < 3; ++i) { lo[i] = kInfF; hi[i] = -kInfF; } }
 void set_box_all(float (&lo)[3], float (&hi)[3]) { for (int i = 0; i < 3; ++i) { lo[i] = -kInfF; hi[i] = kInfF; } }
@@ -652,7 +661,7 @@ uint32_t rt_builder::emit_bvh(Flat& f, const ObjRec& o, int parent, uint32_t dep
     f.nodes.push_back(blank_node());
     const uint32_t r = emit_replay(f, o, 0, parent, depth, need);
     if (r == RT_REF_NONE) return RT_REF_NONE;
-    set_box(f.nodes[gate].lo0, f.nodes[gate].hi0, o.tree[0].box);
+    set_box0_exact(f, gate, o.tree[0].box);
     f.nodes[gate].c0 = r;
     f.nodes[gate].pad[0] = RT_NODE_EXACT;
     return RT_MAKE_REF(RT_REF_NODE, gate);
@@ -693,7 +702,7 @@ uint32_t rt_builder::emit_replay(Flat& f, const ObjRec& o, int node, int parent,
     if (bn.left_node >= 0) c0 = emit_replay(f, o, bn.left_node, parent, depth, n0);
     else c0 = emit(f, bn.left_obj, parent, depth, n0);
     if (c0 == RT_REF_NONE) return RT_REF_NONE;
-    if (bn.left_node >= 0) set_box(f.nodes[me].lo0, f.nodes[me].hi0, o.tree[(size_t)bn.left_node].box);
+    if (bn.left_node >= 0) set_box0_exact(f, me, o.tree[(size_t)bn.left_node].box);
     else set_box_all(f.nodes[me].lo0, f.nodes[me].hi0);
     f.nodes[me].c0 = c0;
     if (bn.right_node >= 0) {
@@ -701,7 +710,7 @@ uint32_t rt_builder::emit_replay(Flat& f, const ObjRec& o, int node, int parent,
         f.nodes.push_back(blank_node());
         const uint32_t r = emit_replay(f, o, bn.right_node, parent, depth, n1);
         if (r == RT_REF_NONE) return RT_REF_NONE;
-        set_box(f.nodes[gate].lo0, f.nodes[gate].hi0, o.tree[(size_t)bn.right_node].box);
+        set_box0_exact(f, gate, o.tree[(size_t)bn.right_node].box);
         f.nodes[gate].c0 = r;
         f.nodes[gate].pad[0] = RT_NODE_EXACT;
         c1 = RT_MAKE_REF(RT_REF_NODE, gate);
@@ -1022,11 +1031,12 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         for (size_t k = sequence.size(); k-- > 0;) { // { child 0: part k, child 1: parts k+1.. under the infinite box }, in that order
             if (sequence[k].ref == RT_REF_NONE) continue;
             RtNode t = blank_node();
-            if (sequence[k].all) set_box_all(t.lo0, t.hi0); else set_box(t.lo0, t.hi0, sequence[k].box);
             t.c0 = sequence[k].ref;
             if (tree_ref != RT_REF_NONE) { set_box_all(t.lo1, t.hi1); t.c1 = tree_ref; }
             t.pad[0] = RT_NODE_ORDERED | RT_NODE_EXACT;
             f.nodes.push_back(t);
+            if (sequence[k].all) set_box_all(f.nodes.back().lo0, f.nodes.back().hi0);
+            else set_box0_exact(f, (uint32_t)f.nodes.size() - 1u, sequence[k].box);
             tree_ref = RT_MAKE_REF(RT_REF_NODE, f.nodes.size() - 1);
             need += 1u;
         }
@@ -1183,6 +1193,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         put_section(blob, hd.perlin_vec, pvec);
         put_section(blob, hd.perlin_perm, pperm);
         put_section(blob, hd.texels, texels);
+        put_section(blob, hd.exact_boxes, f.exact_boxes);
         blob.size = (blob.size + 255u) & ~(size_t)255u;
     };
     BlobOut blob;

@@ -32,6 +32,7 @@ struct DScene {
     const double* perlin_vec;
     const int32_t* perlin_perm;
     const uint8_t* texels;
+    const RtExactBox* exact_boxes;
     uint32_t world, world_flat, world_tree;
     uint32_t n_media;
     uint32_t compat; // bit 0: book-correct RotateY back-rotation; bit 1: book-correct XY lens disk
@@ -82,7 +83,7 @@ RT_HD Ray rt_ray_to_level(const DScene& sc, const Ray& wray, int32_t inst) {
 
 // ---- primitive tests: return t only; the shade stage re-derives p / normal / uv from (ray, t) -------
 
-// AABB::hit (aabb.rs:35-75) on f32 bounds widened to f64, same arithmetic as the reference -
+// AABB::hit (aabb.rs:35-75), same arithmetic as the reference -
 // (bound - origin) * (1/d) per slab - arranged for fewer instructions:
 //   * the near / far bound of each axis is picked by the sign of 1/d instead of swapping t0 and t1 afterwards
 //     (the same two products, selected before instead of after);
@@ -117,7 +118,8 @@ RT_HD RtSlab rt_slab_of(const Ray& r, double extent) {
     s.cnz = (float)(r.o.z * s.inv.z + mz); s.cfz = (float)(r.o.z * s.inv.z - mz);
     return s;
 }
-RT_HD bool rt_aabb_hit(const float (&lo)[3], const float (&hi)[3], const Ray& r, const RtSlab& k, double t_min, double t_max,
+template <class Bound> // float: the node's own copy of the bounds; double: the bounds the reference holds
+RT_HD bool rt_aabb_hit(const Bound (&lo)[3], const Bound (&hi)[3], const Ray& r, const RtSlab& k, double t_min, double t_max,
                        double& t_enter) {
     const double t0x = ((double)(k.nx ? hi[0] : lo[0]) - r.o.x) * k.inv.x;
     const double t1x = ((double)(k.nx ? lo[0] : hi[0]) - r.o.x) * k.inv.x;
@@ -163,7 +165,7 @@ RT_HD RtNode rt_load_node(const RtNode* p) {
     n.lo1[0] = __uint_as_float(b.z); n.lo1[1] = __uint_as_float(b.w); n.lo1[2] = __uint_as_float(c.x);
     n.hi1[0] = __uint_as_float(c.y); n.hi1[1] = __uint_as_float(c.z); n.hi1[2] = __uint_as_float(c.w);
     n.c0 = d.x; n.c1 = d.y;
-    n.pad[0] = d.z; n.pad[1] = 0u;
+    n.pad[0] = d.z; n.pad[1] = d.w;
     return n;
 #else
     return *p;
@@ -432,10 +434,13 @@ struct RtTrav {
 // the reference finds depends on exactly which boxes it tests and with which t_max, so those trees are encoded
 // to replay it: the node is flagged ordered (child 0 first, always), child 1 carries the infinite box and leads to a
 // one-child node holding the real right box, which is therefore tested only after the left subtree is done.
-// Nodes: RtNode load(uint32_t index) - where node records come from (global memory, or a kernel's cached copy).
+// Nodes: RtNode load(uint32_t index), RtExactBox exact_box(uint32_t k) - where node records and the f64 bounds of exact
+// nodes come from (global memory, or a kernel's cached copy).
 struct GlobalNodes {
     const RtNode* nodes;
+    const RtExactBox* exact; // f64 bounds of the boxes whose verdict is behaviour (RtNode::pad[1])
     RT_HD RtNode load(uint32_t index) const { return rt_load_node(nodes + index); }
+    RT_HD RtExactBox exact_box(uint32_t k) const { return exact[k]; }
 };
 // EXACT_NODES = false: for scenes without a node flagged RT_NODE_EXACT (the flag is then not looked at).
 template <bool EXACT_NODES = true, class Stack, class Nodes>
@@ -445,7 +450,12 @@ RT_HD void rt_trav_node_step(const Nodes& nodes, RtTrav& s, Stack& st, double t_
     bool h0, h1, swap;
     if (EXACT_NODES && n.pad[0] != 0u) {
         double e0, e1;
-        h0 = rt_aabb_hit(n.lo0, n.hi0, s.r, s.slab, t_min, s.best.t, e0);
+        if (n.pad[1] != 0u) { // AABB::hit (aabb.rs:35-75) on the f64 bounds the reference's node holds
+            const RtExactBox b = nodes.exact_box(n.pad[1] - 1u);
+            h0 = rt_aabb_hit(b.lo, b.hi, s.r, s.slab, t_min, s.best.t, e0);
+        } else {              // the infinite box in front of an object that has none of its own
+            h0 = rt_aabb_hit(n.lo0, n.hi0, s.r, s.slab, t_min, s.best.t, e0);
+        }
         h1 = rt_aabb_hit(n.lo1, n.hi1, s.r, s.slab, t_min, s.best.t, e1);
         swap = e1 < e0 && (n.pad[0] & RT_NODE_ORDERED) == 0u;
     } else {
@@ -526,6 +536,7 @@ RT_HD void rt_traverse(const DScene& sc, uint32_t root, const Ray& r, double t_m
     s.cur = root;
     GlobalNodes nodes;
     nodes.nodes = sc.nodes;
+    nodes.exact = sc.exact_boxes;
 #pragma unroll 1
     for (;;) {
         rt_trav_descend(nodes, s, st, t_min);

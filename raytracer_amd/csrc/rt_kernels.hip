@@ -123,6 +123,16 @@ struct CachedNodes {
     LdsU4 lds;
     uint32_t n_cached;
     const RtNode* global;
+    const RtExactBox* exact; // f64 bounds of the boxes whose verdict is behaviour (RtNode::pad[1])
+    const __attribute__((address_space(3))) double* exact_lds; // ... and the workgroup's copy of the first n_exact_lds of them
+    uint32_t n_exact_lds;
+    __device__ RtExactBox exact_box(uint32_t k) const {
+        if (k >= n_exact_lds) return exact[k];
+        RtExactBox b;
+        const __attribute__((address_space(3))) double* p = exact_lds + (size_t)k * 6u;
+        b.lo[0] = p[0]; b.lo[1] = p[1]; b.lo[2] = p[2]; b.hi[0] = p[3]; b.hi[1] = p[4]; b.hi[2] = p[5];
+        return b;
+    }
     __device__ static uint32_t place(uint32_t index, uint32_t piece) { return index * 4u + (piece ^ ((index >> 2) & 3u)); }
     __device__ RtNode load(uint32_t index) const {
         u32x4 a, b, c, d; // (d as a full 16-byte read too: a narrower one gets merged with the other branch's into a flat load)
@@ -138,7 +148,7 @@ struct CachedNodes {
         n.lo1[0] = __uint_as_float(b.z); n.lo1[1] = __uint_as_float(b.w); n.lo1[2] = __uint_as_float(c.x);
         n.hi1[0] = __uint_as_float(c.y); n.hi1[1] = __uint_as_float(c.z); n.hi1[2] = __uint_as_float(c.w);
         n.c0 = d.x; n.c1 = d.y;
-        n.pad[0] = d.z; n.pad[1] = 0u;
+        n.pad[0] = d.z; n.pad[1] = d.w;
         return n;
     }
 };
@@ -344,7 +354,7 @@ __device__ unsigned long long g_phase[4][48];
 template <bool EXACT_NODES, bool SPHERE_MEDIA, bool QUERY, bool ALL_CACHED>
 __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
                                                                uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_pct,
-                                                               uint32_t n_cached, QueryBatch qb) {
+                                                               uint32_t n_cached, uint32_t n_exact_lds, QueryBatch qb) {
     extern __shared__ uint4 lds_tree[]; // stack_cap * blockDim.x words of stack, n_cached node records, the queue counter
     const PathRay* rays = pb.ray[it & 1u];
     LiveSet alive_paths;
@@ -378,6 +388,12 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
         nodes.lds = (LdsU4)cache;
         nodes.n_cached = n_cached;
         nodes.global = sc.nodes;
+        nodes.exact = sc.exact_boxes;
+        // behind the node records and the queue counter: the f64 bounds of the exact nodes, when there is room for all of them
+        double* exact_copy = (double*)(cache + (size_t)n_cached * 4u + 1u);
+        for (uint32_t i = threadIdx.x; i < n_exact_lds * 6u; i += blockDim.x) exact_copy[i] = ((const double*)sc.exact_boxes)[i];
+        nodes.exact_lds = (const __attribute__((address_space(3))) double*)exact_copy;
+        nodes.n_exact_lds = n_exact_lds;
         __syncthreads();
     }
     const uint32_t lane = __lane_id();
@@ -820,10 +836,10 @@ int parse_header(rt_context* ctx, const RtBlobHeader& h, size_t nbytes) {
     if (h.stack_need > RT_STACK_CAP) return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "blob: traversal stack need exceeds capacity");
     const RtSection* secs[] = {&h.nodes, &h.spheres, &h.sphere_meta, &h.mspheres, &h.msphere_meta, &h.rects, &h.rect_meta,
                                &h.boxes, &h.box_meta, &h.media, &h.insts, &h.list_entries, &h.materials, &h.textures,
-                               &h.perlin_vec, &h.perlin_perm, &h.texels};
+                               &h.perlin_vec, &h.perlin_perm, &h.texels, &h.exact_boxes};
     const size_t elem[] = {sizeof(RtNode), sizeof(RtSphere), sizeof(RtMeta), sizeof(RtMSphere), sizeof(RtMeta), sizeof(RtRect),
                            sizeof(RtMeta), sizeof(RtBox), sizeof(RtMeta), sizeof(RtMedium), sizeof(RtInst), 4, sizeof(RtMaterial),
-                           sizeof(RtTexture), 8, 4, 1};
+                           sizeof(RtTexture), 8, 4, 1, sizeof(RtExactBox)};
     for (size_t i = 0; i < sizeof(secs) / sizeof(secs[0]); ++i)
         if (secs[i]->offset > nbytes || secs[i]->count * elem[i] > nbytes - secs[i]->offset)
             return ctx_fail(ctx, RT_ERR_INVALID, "blob: section out of range");
@@ -851,6 +867,7 @@ void make_view(rt_scene* s) {
     v.perlin_vec = (const double*)(b + h.perlin_vec.offset);
     v.perlin_perm = (const int32_t*)(b + h.perlin_perm.offset);
     v.texels = (const uint8_t*)(b + h.texels.offset);
+    v.exact_boxes = (const RtExactBox*)(b + h.exact_boxes.offset);
     v.world = RT_REF_NONE;
     v.world_flat = h.world_flat_any_time; // rays of any time (rt_trace_first_hit); a render narrows it, see rt_render_accumulate
     v.world_tree = h.world_tree;
@@ -950,11 +967,11 @@ struct EventTimer { // brackets launches with events when profiling; sums are re
 };
 
 // How k_extend_tree is launched on a scene: which instantiation, and what its one workgroup per CU keeps in LDS.
-typedef void (*ExtendKernel)(DScene, PassInfo, PathBufs, QueueSet, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, QueryBatch);
+typedef void (*ExtendKernel)(DScene, PassInfo, PathBufs, QueueSet, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, QueryBatch);
 struct ExtendLaunch {
     ExtendKernel kernel;
     size_t lds;
-    uint32_t stack_cap, n_cached, refill_min, leaf_pct;
+    uint32_t stack_cap, n_cached, n_exact_lds, refill_min, leaf_pct;
 };
 // `force`: bit 0 = the instantiation with exact f64 box tests even if the scene has no node that needs them, bit 1 = the
 // one with the general medium-boundary code even if every medium is bounded by a sphere (both are valid for any scene).
@@ -965,7 +982,11 @@ int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t f
     const size_t lds_stack_bytes = (size_t)stack_cap * RT_TREE_BLOCK * sizeof(uint32_t);
     if (lds_stack_bytes + 16 > ctx->lds_per_block) return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "render: traversal stacks exceed the LDS of a workgroup");
     const uint32_t n_cached = (uint32_t)std::min<size_t>(sc->hdr.nodes.count, (ctx->lds_per_block - lds_stack_bytes - 16) / sizeof(RtNode));
-    const size_t lds = lds_stack_bytes + (size_t)n_cached * sizeof(RtNode) + 16;
+    size_t lds = lds_stack_bytes + (size_t)n_cached * sizeof(RtNode) + 16;
+    // the f64 bounds of the exact nodes (replay trees: a handful) ride along when all of them fit
+    const size_t exact_bytes = (size_t)sc->hdr.exact_boxes.count * sizeof(RtExactBox);
+    const uint32_t n_exact_lds = lds + exact_bytes <= ctx->lds_per_block ? (uint32_t)sc->hdr.exact_boxes.count : 0u;
+    lds += (size_t)n_exact_lds * sizeof(RtExactBox);
     const bool exact_nodes = sc->hdr.n_exact_nodes != 0u || (force & 1u);
     const bool sphere_media = sc->sphere_media && !(force & 2u);
     // Scheduling thresholds of the traversal kernel, from sweeps (tools/tune.sh): idle lanes of a wave before it draws new
@@ -983,7 +1004,7 @@ int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t f
     if (getenv("RT_DEBUG"))
         fprintf(stderr, "rt: lds_per_block %zu, stack_need %u, nodes %llu, cached %u, lds %zu\n", ctx->lds_per_block, stack_cap,
                 (unsigned long long)sc->hdr.nodes.count, n_cached, lds);
-    out->lds = lds; out->stack_cap = stack_cap; out->n_cached = n_cached;
+    out->lds = lds; out->stack_cap = stack_cap; out->n_cached = n_cached; out->n_exact_lds = n_exact_lds;
     return RT_OK;
 }
 
@@ -1230,7 +1251,7 @@ int rt_trace_first_hit_wavefront(rt_context* ctx, const rt_scene* sc, const rt_r
         qs.error_flag = ctx->error_flag;
         const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min<size_t>((n + RT_TREE_BLOCK - 1) / RT_TREE_BLOCK, (size_t)ctx->n_cu));
         hipLaunchKernelGGL(xl.kernel, dim3(grid), dim3(RT_TREE_BLOCK), xl.lds, ctx->stream, sc->view, pi, pb, qs, 0u, xl.stack_cap,
-                           xl.refill_min, xl.leaf_pct, xl.n_cached, qb);
+                           xl.refill_min, xl.leaf_pct, xl.n_cached, xl.n_exact_lds, qb);
         hipLaunchKernelGGL(k_query_finish, dim3(grid_for(ctx, n, 8)), dim3(RT_BLOCK), 0, ctx->stream, sc->view, qb, d_out);
         e = hipGetLastError();
     }
@@ -1353,7 +1374,7 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
     ExtendLaunch xl;
     rc = extend_launch_of(ctx, sc, false, 0u, &xl);
     if (rc != RT_OK) return rc;
-    const uint32_t stack_cap = xl.stack_cap, refill_min = xl.refill_min, leaf_pct = xl.leaf_pct, n_cached = xl.n_cached;
+    const uint32_t stack_cap = xl.stack_cap, refill_min = xl.refill_min, leaf_pct = xl.leaf_pct, n_cached = xl.n_cached, n_exact_lds = xl.n_exact_lds;
     const size_t lds = xl.lds;
     const ExtendKernel k_extend = xl.kernel;
     const uint32_t extend_blocks_per_cu = 1u;
@@ -1386,7 +1407,7 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
         for (uint32_t it = 0; it < p->max_depth; ++it) {
             a = tm.begin();
             hipLaunchKernelGGL(k_extend, dim3(g_ext), dim3(RT_TREE_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it, stack_cap,
-                               refill_min, leaf_pct, n_cached, no_query);
+                               refill_min, leaf_pct, n_cached, n_exact_lds, no_query);
             tm.end(a, 1);
             a = tm.begin();
             hipLaunchKernelGGL(k_shade_main, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);

@@ -10,7 +10,7 @@
 #include <stdint.h>
 
 #define RT_BLOB_MAGIC 0x31425452u /* "RTB1" little endian */
-#define RT_BLOB_VERSION 12u
+#define RT_BLOB_VERSION 13u
 
 // ---- tagged references -------------------------------------------------------------------------
 enum RtRefType : uint32_t {
@@ -49,8 +49,12 @@ struct RtNode {
     float lo0[3], hi0[3]; // child 0
     float lo1[3], hi1[3]; // child 1
     uint32_t c0, c1;
-    uint32_t pad[2];      // pad[0]: RT_NODE_* flags
+    uint32_t pad[2];      // pad[0]: RT_NODE_* flags; pad[1]: for an RT_NODE_EXACT node whose child-0 box is finite, 1 + the index of that box's f64 bounds in the exact_boxes table (0: none)
 };
+// The f64 bounds of the one real box an RT_NODE_EXACT node carries (child 0's; its child 1 is absent or has the infinite
+// box): the verdict of these box tests is part of what the reference computes, so they run on the bounds the reference
+// holds (aabb.rs:6-9), not on the outward-rounded f32 copy in the node, which a grazing ray could enter and the f64 box not.
+struct RtExactBox { double lo[3], hi[3]; };
 #define RT_NODE_ORDERED 1u /* child 0 is entered (and finished) before child 1 whatever their distances */
 #define RT_NODE_EXACT 2u   /* what the reference finds depends on the verdict of these box tests: they are evaluated in the reference's f64 arithmetic (aabb.rs:35-75); boxes of other nodes only cull and are tested conservatively in f32 */
 
@@ -137,7 +141,7 @@ struct RtBlobHeader {
     double node_extent;        // largest finite |coordinate| of any node box (0 without nodes): scales the error bound of the f32 box test
     uint64_t n_exact_nodes;    // nodes flagged RT_NODE_EXACT
     RtSection nodes, spheres, sphere_meta, mspheres, msphere_meta, rects, rect_meta, boxes, box_meta,
-        media, insts, list_entries, materials, textures, perlin_vec, perlin_perm, texels;
+        media, insts, list_entries, materials, textures, perlin_vec, perlin_perm, texels, exact_boxes;
     // A world tree left for the device to build (RT_BLOB_FLAG_DEVICE_TREE). The compiler has put its leaves, in the order
     // it met them, under a balanced stand-in tree: a node over leaves [s, e) has child 0 over [s, m) and child 1 over
     // [m, e), m = s + (e - s) / 2, down to single leaves. The stand-in is valid (every box bounds what is below it) but

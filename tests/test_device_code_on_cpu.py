@@ -205,3 +205,35 @@ def test_random_scene_graphs_render_like_the_oracle(seed):
     a, _ = ck.hostsim_render(blob, cam, p, 2)
     w, _ = ck.OracleScene(desc, share_bvh_axes=True).render(cam, p, 2, threads=4)
     assert float((util.rel_err(a, w) > 1e-9).mean()) == 0.0 and a.mean() > 0.0
+
+
+def test_replayed_boxes_are_tested_on_their_f64_bounds():
+    """A BvhNode over a RotateY keeps the child's UNROTATED box (hittable.rs:115-143), so whether a ray gets at the rotated
+    geometry depends on the verdict of that box test (aabb.rs:35-75) - on the f64 bounds, which f32 does not hold when they
+    are 0.1, 1.7, 2.9 ...: rays that pass within a fraction of an f32 ulp outside a face of the box must be turned away as
+    the reference turns them away, although the node's own (outward-rounded f32) copy of the box would let them in."""
+    b = api.Builder(seed=11)
+    grey = b.lambertian_color(0.5, 0.5, 0.5)
+    p0, p1 = np.array([0.1, 0.2, 0.3]), np.array([1.7, 2.9, 3.1])
+    box = b.rotate_y(b.box(tuple(p0), tuple(p1), grey), 20.0)
+    other = b.rotate_y(b.box((4.1, 0.3, 0.7), (5.3, 1.9, 2.3), grey), -30.0)
+    world = b.list([b.bvh(b.list([box, other]), 0.0, 1.0)])
+    blob, desc = b.compile(world), b.describe(world)
+    osc = ck.OracleScene(desc, share_bvh_axes=True)
+    rng = np.random.default_rng(3)
+    rays = []
+    for axis in range(3):
+        for bound, sign in ((p0[axis], -1.0), (p1[axis], 1.0)):
+            gap = abs(float(np.float32(bound)) - bound) + np.spacing(np.float32(bound)).astype(np.float64)   # about one f32 ulp
+            n = 4000
+            o = rng.uniform(p0 - 0.5, p1 + 0.5, (n, 3))
+            d = rng.normal(size=(n, 3))
+            d[:, axis] = 0.0                                           # in a plane parallel to the face ...
+            o[:, axis] = bound + sign * rng.uniform(0.0, 1.0, n) * gap  # ... a hair outside it
+            rays.append(util.rays_from(o, d))
+    rays = np.concatenate(rays)
+    want = osc.trace_first_hit(rays)
+    got, _ = ck.hostsim_trace_first_hit(blob, rays)
+    assert np.array_equal(got["prim_id"], want["prim_id"])
+    assert np.array_equal(got["t"].view(np.uint64), want["t"].view(np.uint64))
+    assert (want["prim_id"] == MISS).mean() > 0.5                   # (most of them are turned away; with the f32 copy of the bounds some of those got in)
