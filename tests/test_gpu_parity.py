@@ -127,9 +127,14 @@ def test_random_scene_graphs_on_the_gpu(gpu_ctx, seed):
         rng = np.random.default_rng(1000 + seed)
         rays = util.random_rays(rng, 4000, any_time=flags == 4)
         xi = rng.random((len(rays), osc.n_media)) if osc.n_media else None
-        rep = util.first_hit_report(gpu_ctx.trace_first_hit(scene, rays, xi), osc.trace_first_hit(rays, xi))
+        lane = gpu_ctx.trace_first_hit(scene, rays, xi)
+        rep = util.first_hit_report(lane, osc.trace_first_hit(rays, xi))
         # (media are frequent in these scenes: log() differs in the last bit between the two libms for a few per cent of them)
         assert rep["prim_match"] >= 0.9995 and rep["t_rel_max"] <= 1e-5 and rep["t_bit_equal"] >= 0.95, (seed, flags, rep)
+        # the same rays through the renderer's traversal kernel (frames of their own, nested lists, replay trees, media
+        # on boxes under instances): the same records, byte for byte
+        for variant in (0, 3):
+            assert gpu_ctx.trace_first_hit(scene, rays, xi, wavefront=variant).tobytes() == lane.tobytes(), (seed, flags, variant)
         scene.close()
 
 
