@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             RT_PHASE_ADD(3, 1); RT_PHASE_ADD(4, __popcll(__ballot(at_node)));
             if (at_node) rt_trav_node_step<EXACT_NODES>(nodes, s, st, t_min);
             // a second step before the next look at the wave: the two ballots above cost a sixth of a step (-3.6 % kernel
-            // time; a third and fourth step bring nothing more)
+            // time; a third and fourth step bring nothing more, measured again with the relative leaf threshold)
             if (active && RT_REF_TYPE(s.cur) == RT_REF_NODE) rt_trav_node_step<EXACT_NODES>(nodes, s, st, t_min);
         }
         RT_PHASE_CLOCK(c_nodes1);
