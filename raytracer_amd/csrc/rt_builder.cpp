@@ -998,11 +998,12 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     };
     std::vector<int> world_members;
     if (objs[world].kind == OBJ_LIST) world_members = objs[world].members; else world_members.push_back(world);
-    if (world_members.empty()) return fail(RT_ERR_UNSUPPORTED, "empty scene");
+    // (an empty world is a world: HittableList::hit finds nothing, hittable_list.rs:40-53, and every ray takes the background)
     bool all_monotone = true;
     for (int m : world_members) all_monotone = all_monotone && monotone(m);
     uint32_t flat_ref = RT_REF_NONE, tree_ref = RT_REF_NONE;
-    if (all_monotone) {
+    if (world_members.empty()) {
+    } else if (all_monotone) {
         const Run r = build_run(world_members, true);
         if (run_rc != RT_OK) return run_rc;
         tree_ref = r.ref;
@@ -1055,7 +1056,6 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     } else {
         shutter.lo = -kInf; shutter.hi = kInf;
     }
-    if (flat_ref == RT_REF_NONE && tree_ref == RT_REF_NONE) return fail(RT_ERR_UNSUPPORTED, "empty scene");
     lap("world arranged");
     // Node numbering: breadth-first from the world's root for the first kBreadthFirst records - the traversal kernel keeps
     // a prefix of the node array in LDS, and these are the records nearest the root, which every ray visits - then

@@ -237,3 +237,35 @@ def test_replayed_boxes_are_tested_on_their_f64_bounds():
     assert np.array_equal(got["prim_id"], want["prim_id"])
     assert np.array_equal(got["t"].view(np.uint64), want["t"].view(np.uint64))
     assert (want["prim_id"] == MISS).mean() > 0.5                   # (most of them are turned away; with the f32 copy of the bounds some of those got in)
+
+
+def empty_worlds():
+    """-> [(blob, description)]: a world with nothing in it, one that holds only empty lists (one of them under a RotateY),
+    and one with a sphere between two empty lists. HittableList::hit finds nothing in an empty list (hittable_list.rs:40-53)."""
+    out = []
+    for kind in range(3):
+        b = api.Builder(seed=1)
+        grey = b.lambertian_color(0.5, 0.5, 0.5)
+        if kind == 0:
+            w = b.list()
+        elif kind == 1:
+            w = b.list([b.list(), b.rotate_y(b.list(), 10.0)])
+        else:
+            w = b.list([b.list(), b.sphere((0, 0, 0), 1.0, grey), b.translate(b.list(), (1, 2, 3))])
+        out.append((b.compile(w), b.describe(w)))
+    return out
+
+
+def test_empty_worlds():
+    cam = api.make_camera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40.0, 1.0, 0.0, 5.0, 0.0, 1.0)
+    p = api.make_params(16, 12, max_depth=5, background=(0.25, 0.5, 1.0), seed=3)
+    rays = util.rays_from([(0, 0, 5), (3, 3, 5)], [(0, 0, -1), (0, 0, -1)])
+    for kind, (blob, desc) in enumerate(empty_worlds()):
+        osc = ck.OracleScene(desc)
+        got, segments = ck.hostsim_render(blob, cam, p, 3)
+        want, st = osc.render(cam, p, 3)
+        assert np.array_equal(got, want) and segments == st.ray_segments
+        if kind < 2:
+            assert segments == 16 * 12 * 3 and np.array_equal(got[0, 0], 3 * np.array([0.25, 0.5, 1.0]))   # every ray: the background
+        hit, _ = ck.hostsim_trace_first_hit(blob, rays)
+        assert np.array_equal(hit["prim_id"], osc.trace_first_hit(rays)["prim_id"]) and hit["prim_id"][1] == MISS

@@ -293,3 +293,24 @@ def test_upload_rejects_bad_blobs(gpu_ctx):
     for bad in (blob[:100], b"\0" * len(blob), blob[:-256]):
         with pytest.raises(RtError):
             gpu_ctx.upload(bad)
+
+
+def test_empty_worlds_on_the_gpu(gpu_ctx):
+    """Nothing to hit: every ray of the render takes the background, every query is a miss - in all three kernels."""
+    from test_device_code_on_cpu import empty_worlds
+    cam = api.make_camera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40.0, 1.0, 0.0, 5.0, 0.0, 1.0)
+    p = api.make_params(70, 50, max_depth=5, background=(0.25, 0.5, 1.0), seed=3, spp_per_pass=2)
+    rays = util.rays_from([(0, 0, 5), (3, 3, 5)], [(0, 0, -1), (0, 0, -1)])
+    for kind, (blob, desc) in enumerate(empty_worlds()):
+        osc = ck.OracleScene(desc)
+        scene = gpu_ctx.upload(blob)
+        st = api.rt_stats()
+        got = gpu_ctx.render(scene, cam, p, 3, stats=st)
+        want, ost = osc.render(cam, p, 3)
+        assert util.rel_err(got, want).max() <= 1e-12 and st.ray_segments == ost.ray_segments
+        if kind < 2:
+            assert np.array_equal(got, want) and st.ray_segments == 70 * 50 * 3
+        want_hits = osc.trace_first_hit(rays)["prim_id"]
+        for how in (dict(), dict(wavefront=0), dict(wavefront=3), dict(noalloc=True)):
+            assert np.array_equal(gpu_ctx.trace_first_hit(scene, rays, None, **how)["prim_id"], want_hits), (kind, how)
+        scene.close()
