@@ -314,3 +314,36 @@ def test_empty_worlds_on_the_gpu(gpu_ctx):
         for how in (dict(), dict(wavefront=0), dict(wavefront=3), dict(noalloc=True)):
             assert np.array_equal(gpu_ctx.trace_first_hit(scene, rays, None, **how)["prim_id"], want_hits), (kind, how)
         scene.close()
+
+
+def test_render_parameter_edges(gpu_ctx):
+    """Smallest image, depth 1, no samples, a tile larger than the image, a pass larger than the job, and the arguments
+    the library must refuse - against the oracle where there is something to compare."""
+    _, info, blob, desc = util.build_scene("cornell_smoke")
+    osc = ck.OracleScene(desc, share_bvh_axes=True)
+    scene = gpu_ctx.upload(blob)
+    cam = info.camera
+    # 2 x 2 pixels (the reference divides by width - 1 and height - 1, main.rs:162-163), one bounce: ray_color(depth = 1)
+    p = api.params_from_info(info, width=2, height=2, max_depth=1, seed=util.RENDER_SEED, spp_per_pass=64, tile=128)
+    st = api.rt_stats()
+    got = gpu_ctx.render(scene, cam, p, 5, stats=st)
+    want, ost = osc.render(cam, p, 5)
+    assert util.rel_err(got, want).max() <= 1e-12 and st.ray_segments == ost.ray_segments == 2 * 2 * 5 and st.passes == 1
+    # no samples: nothing happens, the sums stay zero
+    assert not gpu_ctx.render(scene, cam, p, 0).any()
+    # a deep path budget on a small image, odd sizes, pass size that does not divide the job
+    p = api.params_from_info(info, width=37, height=3, max_depth=200, seed=util.RENDER_SEED, spp_per_pass=4)
+    got = gpu_ctx.render(scene, cam, p, 7)
+    want, _ = osc.render(cam, p, 7)
+    assert float((util.rel_err(got, want) > 1e-9).mean()) <= 0.01
+    for bad in (dict(width=1), dict(height=1), dict(max_depth=0), dict(max_depth=70000), dict(tile_rank=2, tile_world=2)):
+        with pytest.raises(api.RtError) as e:
+            gpu_ctx.render(scene, cam, api.params_from_info(info, **dict(dict(width=8, height=8, seed=1), **bad)), 1)
+        assert e.value.code == -1, bad
+    import copy
+    still = copy.copy(cam)
+    still.time0 = still.time1 = 0.5              # gen_range on an empty range panics in the reference (camera.rs:62)
+    with pytest.raises(api.RtError) as e:
+        gpu_ctx.render(scene, still, api.params_from_info(info, width=8, height=8), 1)
+    assert e.value.code == -5
+    scene.close()
