@@ -997,7 +997,7 @@ int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t f
 #define RT_EXT_ROW(E, S) {{k_extend_tree<E, S, false, false>, k_extend_tree<E, S, false, true>}, {k_extend_tree<E, S, true, false>, k_extend_tree<E, S, true, true>}}
     static const ExtendKernel table[2][2][2][2] = {{RT_EXT_ROW(false, false), RT_EXT_ROW(false, true)}, {RT_EXT_ROW(true, false), RT_EXT_ROW(true, true)}};
 #undef RT_EXT_ROW
-    const bool all_cached = n_cached == sc->hdr.nodes.count && !getenv("RT_AB_NOT_ALL_CACHED");
+    const bool all_cached = n_cached == sc->hdr.nodes.count; // every node of the scene has a place in LDS
     out->kernel = table[exact_nodes][sphere_media][query][all_cached];
     if (lds > 65536)
         RT_HIP(hipFuncSetAttribute((const void*)out->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size of k_extend_tree");
