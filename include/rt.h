@@ -71,7 +71,10 @@ int rt_mat_dielectric(rt_builder*, double ir);                        /* Dielect
 int rt_mat_diffuse_light(rt_builder*, int emit_tex, double k);        /* DiffuseLight{emit,k}, material.rs:153-189 */
 int rt_mat_isotropic(rt_builder*, int albedo_tex);                    /* Isotropic, material.rs:207-217 */
 
-/* Hittable (hittable.rs:48-51) */
+/* Hittable (hittable.rs:48-51).
+ * A radius <= 0 is taken as the reference takes it: the surface of radius |r| with the normal turned inwards
+ * (sphere.rs:46), hit like any other sphere in a list; under rt_bvh its inside-out box (sphere.rs:66-72) culls what
+ * the reference's BvhNode would cull (such a tree is kept in the reference's shape and walked in its order). */
 int rt_sphere(rt_builder*, const double center[3], double radius, int mat);                 /* sphere.rs:16 */
 int rt_moving_sphere(rt_builder*, const double c0[3], const double c1[3], double time0, double time1,
                      double radius, int mat);                                               /* moving_sphere.rs:19 */

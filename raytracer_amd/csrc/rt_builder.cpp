@@ -210,7 +210,7 @@ bool rt_builder::bounding_box(int h, double t0, double t1, AABB& out) const {
 }
 
 // Bounds, in the frame `h` lives in, of everything a ray can hit below `h` - true bounds, not the reference's
-// bounding_box(): a BvhNode's box and a primitive's own box are taken as they are, a box carried outward through
+// bounding_box(): a BvhNode's box and a primitive's own box are taken as they are (a sphere's with |radius|), a box carried outward through
 // RotateY is really rotated (the reference's RotateY computes that box and drops it, hittable.rs:117-143), a list is
 // the union of its members, a medium is its boundary. false = unknown (treated as unbounded): a moving sphere, whose
 // extent depends on the shutter interval of the camera that will be used - unless the caller passes `span`: then a
@@ -223,9 +223,19 @@ bool rt_builder::world_bound(int h, AABB& out, TimeSpan* span) const {
         if (!span) return false;
         const double a = std::min(o.d[6], o.d[7]), b = std::max(o.d[6], o.d[7]);
         span->lo = std::max(span->lo, a); span->hi = std::min(span->hi, b);
-        return bounding_box(h, a, b, out);
+        const double r = std::fabs(o.d[8]);
+        for (int i = 0; i < 3; ++i) {
+            const double ca = o.d[i] + (o.d[3 + i] - o.d[i]) * (a - o.d[6]) / (o.d[7] - o.d[6]);
+            const double cb = o.d[i] + (o.d[3 + i] - o.d[i]) * (b - o.d[6]) / (o.d[7] - o.d[6]);
+            out.lo[i] = std::min(ca, cb) - r; out.hi[i] = std::max(ca, cb) + r;
+        }
+        return true;
     }
-    if (o.kind == OBJ_SPHERE || o.kind == OBJ_XYRECT || o.kind == OBJ_XZRECT || o.kind == OBJ_YZRECT || o.kind == OBJ_BOX)
+    if (o.kind == OBJ_SPHERE) { // the surface of a sphere of radius -r is that of radius r
+        for (int i = 0; i < 3; ++i) { out.lo[i] = o.d[i] - std::fabs(o.d[3]); out.hi[i] = o.d[i] + std::fabs(o.d[3]); }
+        return true;
+    }
+    if (o.kind == OBJ_XYRECT || o.kind == OBJ_XZRECT || o.kind == OBJ_YZRECT || o.kind == OBJ_BOX)
         return bounding_box(h, 0.0, 0.0, out);
     if (o.kind == OBJ_MEDIUM) return world_bound(o.child, out, span);
     if (o.kind == OBJ_LIST) {
@@ -1352,6 +1362,9 @@ int rt_sphere(rt_builder* b, const double c[3], double radius, int mat) try {
     if (!b) return RT_ERR_INVALID;
     if (!c || !b->valid_mat(mat)) return b->fail(RT_ERR_INVALID, "sphere: bad argument");
     ObjRec o; o.kind = OBJ_SPHERE; o.mat = mat; o.d[0] = c[0]; o.d[1] = c[1]; o.d[2] = c[2]; o.d[3] = radius;
+    // a radius below zero is hit like any sphere, with the normal turned inwards (sphere.rs:50), but its box comes out
+    // inside out (sphere.rs:66-72): a BvhNode over it culls with a box that does not bound it, and is replayed as such
+    o.exact_bounds = radius > 0.0;
     int id = b->add_obj(o);
     log_fmt(b->log, "sphere %d %a %a %a %a %d\n", id, c[0], c[1], c[2], radius, mat);
     return id;
@@ -1363,7 +1376,7 @@ int rt_moving_sphere(rt_builder* b, const double c0[3], const double c1[3], doub
     ObjRec o; o.kind = OBJ_MSPHERE; o.mat = mat;
     // its box holds for the interval a BvhNode was given, not for every ray time: under RT_BLOB_FLAG_ANY_TIME that
     // counts as a box that does not bound its contents
-    o.exact_bounds = !(b->flags & RT_BLOB_FLAG_ANY_TIME);
+    o.exact_bounds = !(b->flags & RT_BLOB_FLAG_ANY_TIME) && radius > 0.0; // radius <= 0: as for rt_sphere
     for (int i = 0; i < 3; ++i) { o.d[i] = c0[i]; o.d[3 + i] = c1[i]; }
     o.d[6] = time0; o.d[7] = time1; o.d[8] = radius;
     int id = b->add_obj(o);

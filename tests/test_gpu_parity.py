@@ -138,6 +138,25 @@ def test_random_scene_graphs_on_the_gpu(gpu_ctx, seed):
         scene.close()
 
 
+def test_inside_out_spheres_on_the_gpu(gpu_ctx):
+    """Spheres of negative radius: hit like any sphere in a list, cut off under a BvhNode by whatever its box unions leave
+    out (sphere.rs:66-72, bvh.rs:55-60) - the trees the product replays box by box."""
+    for trial in range(6):
+        b, world, in_list, rays = util.inside_out_spheres(trial, 20000)
+        for w in (world, in_list):
+            blob, desc = b.compile(w), b.describe(w)
+            want = ck.OracleScene(desc, share_bvh_axes=True).trace_first_hit(rays)
+            scene = gpu_ctx.upload(blob)
+            lane = gpu_ctx.trace_first_hit(scene, rays)
+            rep = util.first_hit_report(lane, want)
+            assert rep["prim_match"] >= 0.9999 and rep["t_rel_max"] <= 1e-5 and rep["t_bit_equal"] >= 0.98, (trial, rep)
+            hit = rep["both_hit"]
+            assert np.array_equal(lane["flags"][hit], want["flags"][hit])
+            for variant in (0, 3):
+                assert gpu_ctx.trace_first_hit(scene, rays, wavefront=variant).tobytes() == lane.tobytes(), (trial, variant)
+            scene.close()
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_scene_graphs_render_on_the_gpu(gpu_ctx, seed):
     try:

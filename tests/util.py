@@ -187,6 +187,25 @@ def random_scene_graph(seed, flags=0):
     return b, b.list(top)
 
 
+def inside_out_spheres(trial, n_rays=3000):
+    """A BvhNode over spheres and moving spheres of either sign of radius (and a few of radius 0), beside a large and an
+    instanced sphere of negative radius. Returns (builder, world, the same objects in a plain list, rays)."""
+    rng = np.random.default_rng(19 + trial)
+    b = api.Builder(seed=100 + trial)
+    m = b.lambertian_color(0.5, 0.5, 0.5)
+    objs = []
+    for _ in range(int(rng.integers(2, 40))):
+        r = float(rng.uniform(0.3, 2.0)) * (-1.0 if rng.random() < 0.5 else 1.0) * (0.0 if rng.random() < 0.05 else 1.0)
+        c = tuple(rng.uniform(-6, 6, 3))
+        objs.append(b.sphere(c, r, m) if rng.random() < 0.8 else
+                    b.moving_sphere(c, tuple(np.add(c, rng.uniform(-1, 1, 3))), 0.0, 1.0, r, m))
+    rest = [b.sphere((0, -30, 0), -20.0, m), b.translate(b.sphere((1, 1, 1), -1.5, m), (2, 0, 0))]
+    world = b.list([b.bvh(b.list(objs), 0.0, 1.0)] + rest)
+    origins = rng.uniform(-12, 12, (n_rays, 3))
+    rays = rays_from(origins, rng.uniform(-6, 6, (n_rays, 3)) - origins, time=rng.random(n_rays))
+    return b, world, b.list(objs + rest), rays
+
+
 def random_rays(rng, n, any_time=True):
     o = rng.uniform(-14, 14, (n, 3))
     d = rng.normal(size=(n, 3))
