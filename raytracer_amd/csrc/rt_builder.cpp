@@ -217,6 +217,11 @@ bool rt_builder::bounding_box(int h, double t0, double t1, AABB& out) const {
 // moving sphere is bounded over its own [time0, time1] (moving_sphere.rs:71-84), and `span` is narrowed to the ray
 // times for which that bound holds.
 bool rt_builder::world_bound(int h, AABB& out, TimeSpan* span) const {
+    if (!world_bound_any(h, out, span)) return false;
+    for (int i = 0; i < 3; ++i) if (out.lo[i] != out.lo[i] || out.hi[i] != out.hi[i]) return false; // NaN bounds nothing
+    return true;
+}
+bool rt_builder::world_bound_any(int h, AABB& out, TimeSpan* span) const {
     const ObjRec& o = objs[h];
     if (o.kind == OBJ_BVH) { out = o.box; return true; }
     if (o.kind == OBJ_MSPHERE) {
@@ -235,8 +240,12 @@ bool rt_builder::world_bound(int h, AABB& out, TimeSpan* span) const {
         for (int i = 0; i < 3; ++i) { out.lo[i] = o.d[i] - std::fabs(o.d[3]); out.hi[i] = o.d[i] + std::fabs(o.d[3]); }
         return true;
     }
-    if (o.kind == OBJ_XYRECT || o.kind == OBJ_XZRECT || o.kind == OBJ_YZRECT || o.kind == OBJ_BOX)
-        return bounding_box(h, 0.0, 0.0, out);
+    if (o.kind == OBJ_XYRECT || o.kind == OBJ_XZRECT || o.kind == OBJ_YZRECT || o.kind == OBJ_BOX) {
+        // a box with p0 > p1 in one axis keeps the two faces across that axis (_box.rs:22-71); its own box is inside out
+        if (!bounding_box(h, 0.0, 0.0, out)) return false;
+        for (int i = 0; i < 3; ++i) if (out.lo[i] > out.hi[i]) std::swap(out.lo[i], out.hi[i]);
+        return true;
+    }
     if (o.kind == OBJ_MEDIUM) return world_bound(o.child, out, span);
     if (o.kind == OBJ_LIST) {
         if (o.members.empty()) return false;
@@ -277,6 +286,20 @@ bool rt_builder::has_moving(int h) const {
         return false;
     case OBJ_BVH:
         for (int m : objs[o.child].members) if (has_moving(m)) return true;
+        return false;
+    default: return false;
+    }
+}
+bool rt_builder::has_medium(int h) const {
+    const ObjRec& o = objs[h];
+    switch (o.kind) {
+    case OBJ_MEDIUM: return true;
+    case OBJ_TRANSLATE: case OBJ_ROTATE_Y: return has_medium(o.child);
+    case OBJ_LIST:
+        for (int m : o.members) if (has_medium(m)) return true;
+        return false;
+    case OBJ_BVH:
+        for (int m : objs[o.child].members) if (has_medium(m)) return true;
         return false;
     default: return false;
     }
@@ -636,7 +659,7 @@ typedef std::function<uint32_t(int, uint32_t&)> LeafFn;
 static uint32_t emit_ordered(rt_builder::Flat& f, const std::vector<TNode>& tree, const Kid& k, const LeafFn& leaf, uint32_t& need);
 
 uint32_t rt_builder::emit_bvh(Flat& f, const ObjRec& o, int parent, uint32_t depth, uint32_t& need) {
-    if (o.exact_bounds) {
+    if (o.exact_bounds && !literal) {
         limit_time(o);
         std::vector<TNode> tree;
         Kid root;
@@ -667,6 +690,11 @@ uint32_t rt_builder::emit_bvh(Flat& f, const ObjRec& o, int parent, uint32_t dep
         return emit_ordered(f, tree, root, [&](int obj, uint32_t& n) { return emit(f, obj, parent, depth, n); }, need);
     }
     // Replay form: the root's own box first (bvh.rs:113), in front of the root node.
+    if (o.tree.empty()) { // rt_bvh skipped the reference's build (RT_BLOB_FLAG_DEVICE_TREE) before anything asked for it
+        fail(RT_ERR_UNSUPPORTED, "BvhNode built without its shape under RT_BLOB_FLAG_DEVICE_TREE, and an object constructed later "
+                                 "(a moving sphere with time0 == time1) makes the scene depend on it: construct that object first, or drop the flag");
+        return RT_REF_NONE;
+    }
     const uint32_t gate = (uint32_t)f.nodes.size();
     f.nodes.push_back(blank_node());
     const uint32_t r = emit_replay(f, o, 0, parent, depth, need);
@@ -724,9 +752,11 @@ uint32_t rt_builder::emit_replay(Flat& f, const ObjRec& o, int node, int parent,
         f.nodes[gate].c0 = r;
         f.nodes[gate].pad[0] = RT_NODE_EXACT;
         c1 = RT_MAKE_REF(RT_REF_NODE, gate);
-    } else if (bn.right_obj != bn.left_obj || objs[bn.right_obj].kind == OBJ_MEDIUM) {
-        // span-1 nodes (bvh.rs:33-35) hold the same object twice; the second test can never win for a
-        // surface, so it is dropped. A medium keeps both tests.
+    } else if (bn.right_obj != bn.left_obj || literal || has_medium(bn.right_obj)) {
+        // span-1 nodes (bvh.rs:33-35) hold the same object twice; the second test, against the t of the first, can
+        // never win for surfaces, so it is dropped. Anything with a medium in it keeps both tests (the medium is asked
+        // again with t_max = its own t, or, where its density is negative, finds what the first round culled), and so
+        // does a scene compiled literally.
         c1 = emit(f, bn.right_obj, parent, depth, n1);
         if (c1 == RT_REF_NONE) return RT_REF_NONE;
     }
@@ -779,7 +809,27 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     // (hittable_list.rs:45-51). Such an entry is a barrier: the entries before it, the entry, and the entries after it
     // are kept in that order (nodes flagged as ordered), and only the runs between barriers are rearranged as above,
     // without a lock-step list.
+    // After a hit at t = NaN the closest hit does depend on the order of what is tested next, anywhere in the scene:
+    // `t < NaN` is false, so a sphere or a box is never hit and AABB::hit passes every ray (aabb.rs:43-47), but a rectangle,
+    // a moving sphere or a medium lets NaN through its comparisons (aarect.rs:26-28, moving_sphere.rs:56-60) and brings
+    // t back to a number. A scene that holds something reporting such hits is compiled literally: every list in its
+    // order, every BvhNode in the reference's shape with the reference's boxes.
+    std::function<bool(int)> nan_hits = [&](int h) -> bool {
+        const ObjRec& o = objs[h];
+        switch (o.kind) {
+        case OBJ_TRANSLATE: case OBJ_ROTATE_Y: case OBJ_MEDIUM: return nan_hits(o.child);
+        case OBJ_LIST:
+            for (int m : o.members) if (nan_hits(m)) return true;
+            return false;
+        case OBJ_BVH:
+            for (int m : objs[o.child].members) if (nan_hits(m)) return true;
+            return false;
+        default: return o.nan_hits;
+        }
+    };
+    literal = nan_hits(world);
     std::function<bool(int)> monotone = [&](int h) -> bool {
+        if (literal) return false;
         const ObjRec& o = objs[h];
         switch (o.kind) {
         case OBJ_TRANSLATE: case OBJ_ROTATE_Y: return monotone(o.child);
@@ -790,7 +840,8 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
             if (!o.exact_bounds) return false;
             for (int m : objs[o.child].members) if (!monotone(m)) return false;
             return true;
-        default: return true;
+        case OBJ_MEDIUM: return o.monotone && monotone(o.child);
+        default: return o.monotone;
         }
     };
     struct Item { int handle; bool bounded; AABB box; bool flatable; bool timed; int wrapped; };
@@ -845,7 +896,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
                     for (int sub : *subs) {
                         Item it;
                         it.handle = sub; it.flatable = false; it.timed = false;
-                        it.bounded = bounding_box(sub, 0.0, 0.0, it.box);
+                        it.bounded = world_bound(sub, it.box, nullptr);
                         if (!it.bounded) { run_rc = fail(RT_ERR_PANIC, "No bounding box"); return out; }
                         const bool ball = objs[sub].kind == OBJ_SPHERE;
                         double c[3] = {objs[sub].d[0], objs[sub].d[1], objs[sub].d[2]};
@@ -1377,6 +1428,10 @@ int rt_moving_sphere(rt_builder* b, const double c0[3], const double c1[3], doub
     // its box holds for the interval a BvhNode was given, not for every ray time: under RT_BLOB_FLAG_ANY_TIME that
     // counts as a box that does not bound its contents
     o.exact_bounds = !(b->flags & RT_BLOB_FLAG_ANY_TIME) && radius > 0.0; // radius <= 0: as for rt_sphere
+    // time0 == time1: center() divides by zero (moving_sphere.rs:37-40), the discriminant is NaN, and hit() lets NaN
+    // through all of its comparisons (moving_sphere.rs:51-60): every ray "hits" at t = NaN, and whatever a list tests
+    // after it is compared against that
+    if (!(time0 != time1) || !(std::fabs(time0) < kInf) || !(std::fabs(time1) < kInf)) { o.monotone = o.exact_bounds = false; o.nan_hits = true; b->seen_nan_hits = true; }
     for (int i = 0; i < 3; ++i) { o.d[i] = c0[i]; o.d[3 + i] = c1[i]; }
     o.d[6] = time0; o.d[7] = time1; o.d[8] = radius;
     int id = b->add_obj(o);
@@ -1389,6 +1444,9 @@ static int add_rect(rt_builder* b, ObjKind kind, const char* name, double a0, do
     if (!b) return RT_ERR_INVALID;
     if (!b->valid_mat(mat)) return b->fail(RT_ERR_INVALID, "%s: bad material handle %d", name, mat);
     ObjRec o; o.kind = kind; o.mat = mat; o.d[0] = a0; o.d[1] = a1; o.d[2] = b0; o.d[3] = b1; o.d[4] = k;
+    // without extent in one of its axes its box has none either, and AABB::hit (aabb.rs:35-75) never passes a box
+    // without volume, except on NaN: a BvhNode over it is replayed with the reference's boxes
+    o.exact_bounds = a0 < a1 && b0 < b1;
     int id = b->add_obj(o);
     log_fmt(b->log, "%s %d %a %a %a %a %a %d\n", name, id, a0, a1, b0, b1, k, mat);
     return id;
@@ -1407,6 +1465,9 @@ int rt_box(rt_builder* b, const double p0[3], const double p1[3], int mat) try {
     if (!p0 || !p1 || !b->valid_mat(mat)) return b->fail(RT_ERR_INVALID, "box: bad argument");
     ObjRec o; o.kind = OBJ_BOX; o.mat = mat;
     for (int i = 0; i < 3; ++i) { o.d[i] = p0[i]; o.d[3 + i] = p1[i]; }
+    // a flat box still has faces that a list hits, but its own box (_box.rs:81-84) has no volume (see add_rect); one
+    // with p0 > p1 in some axis has hittable faces outside an inside-out box
+    o.exact_bounds = p0[0] < p1[0] && p0[1] < p1[1] && p0[2] < p1[2];
     int id = b->add_obj(o);
     log_fmt(b->log, "box %d %a %a %a %a %a %a %d\n", id, p0[0], p0[1], p0[2], p1[0], p1[1], p1[2], mat);
     return id;
@@ -1458,7 +1519,11 @@ int rt_constant_medium(rt_builder* b, int boundary, double density, double r, do
     b->texs.push_back(t);
     int mat = add_mat(b, RT_MAT_ISOTROPIC, (int)b->texs.size() - 1, 0, 0, 0, 0);
     ObjRec o; o.kind = OBJ_MEDIUM; o.child = boundary; o.mat = mat; o.d[0] = -1.0 / density;
-    o.exact_bounds = b->objs[boundary].exact_bounds;
+    // A density below zero (or NaN) scatters at a distance below zero, in front of the point where the ray enters -
+    // possibly below t_min (constant_medium.rs:56-61): what such a medium reports depends on the t_max it is asked
+    // with, so on what was tested before it. It keeps its place in the reference's order, and so does a tree over it.
+    o.monotone = o.d[0] <= 0.0;
+    o.exact_bounds = b->objs[boundary].exact_bounds && o.monotone;
     o.medium_index = b->n_media++;
     int id = b->add_obj(o);
     log_fmt(b->log, "constant_medium %d %d %a %a %a %a %d %d\n", id, boundary, density, r, g, bl, mat, (int)b->texs.size() - 1);
@@ -1498,7 +1563,7 @@ int rt_bvh(rt_builder* b, int list, double t0, double t1) try {
     // With the tree left to the device (flag bit 3) a BvhNode whose boxes all bound their contents is never emitted in
     // the reference's shape - it is a set of objects and their bound - so the reference's build (a sort per level,
     // bvh.rs:26-63) is skipped; what remains of it is the root's box (bvh.rs:55-64: the union of the members' boxes).
-    const bool shape_unused = o.exact_bounds && (b->flags & RT_BLOB_FLAG_DEVICE_TREE) && !(b->flags & RT_BLOB_FLAG_REFERENCE_TREE);
+    const bool shape_unused = o.exact_bounds && (b->flags & RT_BLOB_FLAG_DEVICE_TREE) && !(b->flags & RT_BLOB_FLAG_REFERENCE_TREE) && !b->seen_nan_hits;
     if (shape_unused) {
         // the axis draws of the skipped constructor calls (bvh.rs:22, one per BvhNode::new) are still made, in the same
         // order: what the scene code draws afterwards (Perlin tables, the next tree) must not depend on the flag

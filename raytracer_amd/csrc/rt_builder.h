@@ -46,6 +46,10 @@ struct ObjRec {
     // bounding_box() really contains the object. False for RotateY (keeps the child's unrotated box, hittable.rs:115-143)
     // and HittableList (last member's box only, hittable_list.rs:55-75) and whatever is built on them.
     bool exact_bounds = true;
+    // hit(r, t_min, t_max) reports its nearest hit below t_max whatever t_max is. False for what can report a t that is
+    // NaN or lies outside (t_min, t_max): the answer of a list over it depends on the order of the list.
+    bool monotone = true;
+    bool nan_hits = false;     // reports hits at t = NaN: a list compares everything it tests afterwards against NaN
 };
 struct MatRec {
     uint32_t type = 0;
@@ -80,8 +84,11 @@ struct rt_builder {
     std::vector<uint8_t> log; // constructor log as compact records (rt_builder.cpp: log_fmt / log_text)
     std::string axis_log; // split axes of the BVH being built, one digit per BvhNode::new call
     std::string error;
+    bool seen_nan_hits = false; // an object that reports hits at t = NaN has been constructed
+    bool literal = false; // set by compile(): every list and BvhNode keeps the reference's order of tests
     double valid_lo = -std::numeric_limits<double>::infinity(), valid_hi = std::numeric_limits<double>::infinity(); // set by compile()
     bool has_moving(int h) const; // a moving sphere somewhere below h
+    bool has_medium(int h) const; // a ConstantMedium somewhere below h, or h itself
     void limit_time(const ObjRec& bvh);
 
     int fail(int code, const char* fmt, ...);
@@ -92,6 +99,7 @@ struct rt_builder {
     bool bounding_box(int h, double t0, double t1, AABB& out) const;
     struct TimeSpan { double lo, hi; };
     bool world_bound(int h, AABB& out, TimeSpan* span = nullptr) const;
+    bool world_bound_any(int h, AABB& out, TimeSpan* span) const; // may hold NaN
     int build_bvh_node(std::vector<BNode>& tree, std::vector<int>& objects, const std::vector<double>& keys, size_t start,
                        size_t end, double t0, double t1);
     uint32_t emit(Flat& f, int h, int parent, uint32_t depth, uint32_t& need);

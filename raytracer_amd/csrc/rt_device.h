@@ -449,15 +449,18 @@ RT_HD void rt_trav_node_step(const Nodes& nodes, RtTrav& s, Stack& st, double t_
     RT_VISIT(0u);
     bool h0, h1, swap;
     if (EXACT_NODES && n.pad[0] != 0u) {
-        double e0, e1;
+        // Such a node has one real box at most, child 0's, held in f64 (the f32 copy in the record is for code that only
+        // culls); its other boxes stand in front of objects that the reference tests without asking a box (a list's
+        // entries, hittable_list.rs:45-51; a BvhNode's object children, bvh.rs:116-121): those are entered whatever the
+        // closest distance has become - below t_min or NaN included - and child 0 always goes first.
+        h0 = true;
         if (n.pad[1] != 0u) { // AABB::hit (aabb.rs:35-75) on the f64 bounds the reference's node holds
+            double e0;
             const RtExactBox b = nodes.exact_box(n.pad[1] - 1u);
             h0 = rt_aabb_hit(b.lo, b.hi, s.r, s.slab, t_min, s.best.t, e0);
-        } else {              // the infinite box in front of an object that has none of its own
-            h0 = rt_aabb_hit(n.lo0, n.hi0, s.r, s.slab, t_min, s.best.t, e0);
         }
-        h1 = rt_aabb_hit(n.lo1, n.hi1, s.r, s.slab, t_min, s.best.t, e1);
-        swap = e1 < e0 && (n.pad[0] & RT_NODE_ORDERED) == 0u;
+        h1 = true;
+        swap = false;
     } else {
         const float lo = (float)t_min, hi = (float)s.best.t; // widened by an ulp each: the conversions round to nearest
         float e0, e1;

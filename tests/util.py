@@ -187,6 +187,92 @@ def random_scene_graph(seed, flags=0):
     return b, b.list(top)
 
 
+def hostile_scene_graph(seed, flags=0):
+    """random_scene_graph's ill-natured sibling: the same nestings over parameters no sane scene has - radii that are
+    negative, zero or tiny, rectangles and boxes that are flat or inside out, moving spheres whose interval is empty
+    (centre = x / 0, moving_sphere.rs:37-40) or reversed, rotations by 0, 90, 360 and 720.5 degrees, translations by
+    nothing and by 1e7, media of density 0, -0.3, 1e-12 and 1e6 on boundaries that cannot be entered, BvhNodes over one
+    member, over time intervals that miss their moving spheres, empty lists. The reference takes all of it without
+    complaint and what it then computes is well defined, if not meaningful; the product has to compute the same.
+    -> (builder, world handle); raises api.RtError where the reference panics (a BvhNode over something without a box)
+    or the product declines (deeper instance chains than it supports)."""
+    rng = np.random.default_rng(5000 + seed)
+    b = api.Builder(seed=900 + seed, flags=flags)
+    mats = [b.lambertian_color(0.6, 0.5, 0.4), b.metal(0.8, 0.8, 0.7, 0.2), b.dielectric(1.5)]
+
+    def pick(xs):
+        return xs[int(rng.integers(len(xs)))]
+
+    def prim():
+        k = int(rng.integers(6))
+        c = rng.uniform(-6, 6, 3)
+        if k == 0:
+            return b.sphere(tuple(c), float(pick([-2.0, 0.0, 1e-9, 1.0, 2.5, 50.0])), pick(mats))
+        if k == 1:
+            t0, t1 = pick([(0.0, 1.0), (1.0, 0.0), (0.25, 0.75), (2.0, 3.0), (0.5, 0.5)])
+            c1 = c if rng.random() < 0.2 else c + rng.uniform(-2, 2, 3)
+            return b.moving_sphere(tuple(c), tuple(c1), t0, t1, float(pick([-1.5, 0.0, 1.0, 2.0])), pick(mats))
+        if k == 5:
+            d = rng.uniform(0.5, 4.0, 3) * np.array([pick([1.0, 1.0, 0.0, -1.0]) for _ in range(3)])
+            return b.box(tuple(c), tuple(c + d), pick(mats))
+        a0, b0 = rng.uniform(-6, 4, 2)
+        a1, b1 = a0 + rng.uniform(0.5, 6) * pick([1.0, 1.0, 0.0, -1.0]), b0 + rng.uniform(0.5, 6) * pick([1.0, 1.0, 0.0, -1.0])
+        rect = (b.xy_rect, b.xz_rect, b.yz_rect)[k - 2]
+        return rect(float(a0), float(a1), float(b0), float(b1), float(pick([0.0, -3.0, 4.5, 1e6])), pick(mats))
+
+    def wrapped(h, most=3):
+        for _ in range(int(rng.integers(0, most + 1))):
+            if rng.random() < 0.5:
+                h = b.translate(h, tuple(pick([np.zeros(3), rng.uniform(-4, 4, 3), np.array([1e7, 0, 0]), np.array([0, -0.0, 0])])))
+            else:
+                h = b.rotate_y(h, float(pick([0.0, 90.0, -90.0, 180.0, 360.0, 1e-9, 720.5, 45.0, -33.0])))
+        return h
+
+    def medium():
+        kind = int(rng.integers(5))
+        if kind == 0:
+            boundary = b.sphere(tuple(rng.uniform(-5, 5, 3)), float(pick([3.0, -3.0, 0.0])), mats[0])
+        elif kind == 1:
+            boundary = b.box(tuple(rng.uniform(-6, 0, 3)), tuple(rng.uniform(-1, 6, 3)), mats[0])
+        elif kind == 2:
+            boundary = b.xz_rect(-3, 3, -3, 3, 1.0, mats[0])
+        elif kind == 3:
+            boundary = b.moving_sphere((0, 0, 0), (1, 1, 0), 0.0, 1.0, 2.5, mats[0])
+        else:
+            boundary = prim()
+        return b.constant_medium(wrapped(boundary, 2), float(pick([0.0, -0.3, 1e-12, 0.2, 1.0, 1e6])), 0.8, 0.8, 0.9)
+
+    def leafish():
+        r = rng.random()
+        if r < 0.2:
+            return medium()
+        return wrapped(prim(), 2) if r < 0.6 else prim()
+
+    def group(level):
+        members = []
+        for _ in range(int(rng.integers(1, 6)) if rng.random() > 0.04 else 0):
+            members.append(group(level - 1) if level > 0 and rng.random() < 0.3 else leafish())
+        lst = b.list(members)
+        r = rng.random()
+        if r < 0.6 and members:
+            return wrapped(b.bvh(lst, *pick([(0.0, 1.0), (0.0, 0.0), (5.0, 6.0)])), 1)
+        return lst if r < 0.8 else wrapped(lst, 1)
+
+    top = []
+    for _ in range(int(rng.integers(2, 8))):
+        top.append(group(2) if rng.random() < 0.5 else leafish())
+    return b, b.list(top)
+
+
+def same_first_hits(a, b, t_rel=0.0):
+    """Two sets of first-hit records of the same rays, where t may be NaN, negative or infinite: the same primitive and
+    the same t (to the bit for t_rel = 0, NaN equal to NaN) -> fraction of rays that agree."""
+    ta, tb = a["t"], b["t"]
+    with np.errstate(invalid="ignore"):
+        t_ok = (ta == tb) | (np.isnan(ta) & np.isnan(tb)) | (np.abs(ta - tb) <= t_rel * np.abs(tb))
+    return float(((a["prim_id"] == b["prim_id"]) & t_ok).mean())
+
+
 def inside_out_spheres(trial, n_rays=3000):
     """A BvhNode over spheres and moving spheres of either sign of radius (and a few of radius 0), beside a large and an
     instanced sphere of negative radius. Returns (builder, world, the same objects in a plain list, rays)."""
