@@ -74,7 +74,13 @@ int rt_mat_isotropic(rt_builder*, int albedo_tex);                    /* Isotrop
 /* Hittable (hittable.rs:48-51).
  * A radius <= 0 is taken as the reference takes it: the surface of radius |r| with the normal turned inwards
  * (sphere.rs:46), hit like any other sphere in a list; under rt_bvh its inside-out box (sphere.rs:66-72) culls what
- * the reference's BvhNode would cull (such a tree is kept in the reference's shape and walked in its order). */
+ * the reference's BvhNode would cull (such a tree is kept in the reference's shape and walked in its order).
+ * Other parameters without sense are not refused either, since the reference computes something definite for them:
+ * a rect or box without extent in an axis (hit in a list, never under rt_bvh: AABB::hit passes no box without
+ * volume, aabb.rs:47), a box with p0 > p1 (keeps the faces across that axis), a medium of density < 0 (scatters in
+ * front of its boundary; what it reports depends on what was tested before it, constant_medium.rs:40-61), a moving
+ * sphere with time0 == time1 (every ray hits it at t = NaN, moving_sphere.rs:37-60). Scenes holding the last two are
+ * walked in the reference's order of tests throughout, which costs speed, not results. */
 int rt_sphere(rt_builder*, const double center[3], double radius, int mat);                 /* sphere.rs:16 */
 int rt_moving_sphere(rt_builder*, const double c0[3], const double c1[3], double time0, double time1,
                      double radius, int mat);                                               /* moving_sphere.rs:19 */
