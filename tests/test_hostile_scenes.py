@@ -195,6 +195,52 @@ def test_hostile_scene_graphs_render(seed):
     assert close.all()
 
 
+def sane_scene(seed, flags):
+    try:
+        b, world = util.random_scene_graph(seed, flags)
+        return b.compile(world), b.describe(world)
+    except api.RtError as e:
+        assert e.code == -2
+        return None
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_hostile_rays(seed):
+    """Well-formed scenes, ill-formed rays (see util.hostile_rays)."""
+    for flags in (0, api.FLAG_ANY_TIME):
+        made = sane_scene(seed, flags)
+        if made is None:
+            continue
+        blob, desc = made
+        osc = ck.OracleScene(desc, share_bvh_axes=True)
+        rng = np.random.default_rng(300 + seed)
+        rays = util.hostile_rays(rng, 3000)
+        xi = rng.random((len(rays), osc.n_media)) if osc.n_media else None
+        got, _ = ck.hostsim_trace_first_hit(blob, rays, xi)
+        assert util.same_first_hits(got, osc.trace_first_hit(rays, xi)) == 1.0, (seed, flags)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(0, 40, 4))
+def test_hostile_rays_on_the_gpu(gpu_ctx, seed):
+    made = sane_scene(seed, api.FLAG_ANY_TIME)
+    if made is None:
+        pytest.skip("deeper instance chains than the product supports")
+    blob, desc = made
+    osc = ck.OracleScene(desc, share_bvh_axes=True)
+    rng = np.random.default_rng(300 + seed)
+    rays = util.hostile_rays(rng, 30000)
+    xi = rng.random((len(rays), osc.n_media)) if osc.n_media else None
+    scene = gpu_ctx.upload(blob)
+    lane = gpu_ctx.trace_first_hit(scene, rays, xi)
+    want = osc.trace_first_hit(rays, xi)
+    assert util.same_first_hits(lane, want, t_rel=1e-12) >= 0.9995, seed
+    assert util.same_first_hits(lane, want) >= 0.95, seed
+    for variant in (0, 3):
+        assert util.same_first_hits(gpu_ctx.trace_first_hit(scene, rays, xi, wavefront=variant), lane) == 1.0, (seed, variant)
+    scene.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(0, 60, 3))
 def test_hostile_scene_graphs_on_the_gpu(gpu_ctx, seed):

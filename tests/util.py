@@ -273,6 +273,30 @@ def same_first_hits(a, b, t_rel=0.0):
     return float(((a["prim_id"] == b["prim_id"]) & t_ok).mean())
 
 
+def hostile_rays(rng, n):
+    """random_rays with a share of rays along an axis (zero direction components: 1/0 in every box test, x/0 in the
+    rectangles), with intervals (t_min, t_max) that are empty, negative or start at 0, and with directions scaled by
+    1e-100 ... 1e100. Left out, because the product does not follow the reference there: a ray lying exactly in the plane
+    of a rectangle (0/0: the reference reports a hit at t = NaN wherever the rectangle is, aarect.rs:22-33; the product
+    only if the ray also passes the rectangle's bounds), and directions whose squared length overflows or underflows."""
+    r = random_rays(rng, n, any_time=False)
+    kind = rng.integers(0, 6, n)
+    for i in np.nonzero(kind == 0)[0]:
+        d = np.zeros(3)
+        d[rng.integers(3)] = rng.choice([-1.0, 1.0]) * rng.uniform(0.1, 3)
+        if rng.random() < 0.3:
+            d[rng.integers(3)] = rng.uniform(-2, 2)
+        r["dx"][i], r["dy"][i], r["dz"][i] = d
+    odd = kind == 1
+    r["tmin"][odd] = rng.choice([0.0, -5.0, 3.0, 1e-9], int(odd.sum()))
+    r["tmax"][odd] = rng.choice([np.inf, 4.0, 12.0, 1e-3, -1.0], int(odd.sum()))
+    scaled = kind == 2
+    s = rng.choice([1e-100, 1e100, 1e-30, 1e30, 1e-5], int(scaled.sum()))
+    for f in ("dx", "dy", "dz"):
+        r[f][scaled] *= s
+    return r
+
+
 def inside_out_spheres(trial, n_rays=3000):
     """A BvhNode over spheres and moving spheres of either sign of radius (and a few of radius 0), beside a large and an
     instanced sphere of negative radius. Returns (builder, world, the same objects in a plain list, rays)."""
