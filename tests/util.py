@@ -297,6 +297,62 @@ def hostile_rays(rng, n):
     return r
 
 
+def hostile_materials_scene(seed):
+    """Plain geometry under materials and textures no one would choose: albedos above 1 and below 0, fuzz of 5 and -1,
+    refractive indices 0, 1, -1.5, 1e-9 and 1e9, lights of strength 0 and -2, noise of scale 0 and 1e6, images of one
+    texel, checkers of checkers - on spheres, boxes, rectangles, an instanced sphere and a medium. -> (builder, world)."""
+    rng = np.random.default_rng(7000 + seed)
+    b = api.Builder(seed=40 + seed)
+
+    def pick(xs):
+        return xs[int(rng.integers(len(xs)))]
+
+    def tex(depth=0):
+        k = int(rng.integers(5 if depth < 3 else 3))
+        if k == 0:
+            return b.solid(*[float(pick([0.0, 0.5, 1.0, 1.5, -0.2, 1e3])) for _ in range(3)])
+        if k == 1:
+            return b.noise(float(pick([0.0, 4.0, -3.0, 1e6, 1e-9])))
+        if k == 2:
+            h, w = int(pick([1, 2, 5])), int(pick([1, 3, 8]))
+            return b.image(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+        return b.checker(tex(depth + 1), tex(depth + 1))
+
+    def mat():
+        k = int(rng.integers(5))
+        if k == 0:
+            return b.lambertian(tex())
+        if k == 1:
+            return b.metal(*[float(pick([0.0, 0.7, 1.0, 2.0, -0.5])) for _ in range(3)], float(pick([0.0, 0.3, 1.0, 5.0, -1.0])))
+        if k == 2:
+            return b.dielectric(float(pick([1.5, 1.0, 0.0, -1.5, 1e-9, 1e9, 0.5])))
+        if k == 3:
+            return b.diffuse_light(tex(), float(pick([1.0, 0.0, -2.0, 15.0])))
+        return b.isotropic(tex())
+
+    objs = []
+    for _ in range(int(rng.integers(8, 30))):
+        c = rng.uniform(-6, 6, 3)
+        k = int(rng.integers(4))
+        if k == 0:
+            objs.append(b.sphere(tuple(c), float(rng.uniform(0.5, 3)), mat()))
+        elif k == 1:
+            objs.append(b.box(tuple(c), tuple(c + rng.uniform(0.5, 4, 3)), mat()))
+        elif k == 2:
+            a0, b0 = rng.uniform(-6, 4, 2)
+            objs.append(pick([b.xy_rect, b.xz_rect, b.yz_rect])(float(a0), float(a0 + rng.uniform(1, 6)), float(b0),
+                                                             float(b0 + rng.uniform(1, 6)), float(rng.uniform(-6, 6)), mat()))
+        else:
+            objs.append(b.rotate_y(b.translate(b.sphere(tuple(c), float(rng.uniform(0.5, 2)), mat()), (1, 0, 0)), 30.0))
+    if rng.random() < 0.5:
+        objs.append(b.constant_medium(b.sphere((0, 0, 0), 5.0, mat()), float(pick([0.05, 0.3])),
+                                      *[float(pick([0.0, 0.9, 1.0, 2.0])) for _ in range(3)]))
+    if rng.random() < 0.5:                                                  # a room around it all: no path gets away early
+        objs.append(b.sphere((0, 0, 0), 40.0, mat()))
+    half = len(objs) // 2 + 1
+    return b, b.list([b.bvh(b.list(objs[:half]), 0.0, 1.0)] + objs[half:])
+
+
 def inside_out_spheres(trial, n_rays=3000):
     """A BvhNode over spheres and moving spheres of either sign of radius (and a few of radius 0), beside a large and an
     instanced sphere of negative radius. Returns (builder, world, the same objects in a plain list, rays)."""
