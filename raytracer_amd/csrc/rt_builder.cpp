@@ -15,6 +15,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <map>
 
 namespace {
 
@@ -359,11 +360,37 @@ struct rt_builder::Flat {
     std::vector<RtInst> insts;
     std::vector<uint32_t> list_entries;
     std::vector<RtExactBox> exact_boxes; // f64 bounds of the child-0 boxes of RT_NODE_EXACT nodes (RtNode::pad[1])
+    std::vector<RtChain> chains;         // Translate / RotateY sequences above RT_REF_ILEAF primitives, each kept once
+    std::map<std::vector<int>, std::pair<int, int>> pushed_chains; // instance handles outermost first -> (innermost of the RtInst records made for them, chain) for members pushed down to the leaves
+    int ileaf_off = 0;                   // > 0 while emitting something that is walked through RtInst records (a medium's boundary)
     uint32_t max_chain = 0;
     uint32_t n_media = 0;
 };
 
 namespace {
+// The chain record with these steps (found or added), or -1 when the table is full.
+int chain_of(std::vector<RtChain>& chains, const std::vector<RtChainOp>& ops) {
+    if (ops.empty() || ops.size() > (size_t)RT_MAX_CHAIN) return -1;
+    RtChain c;
+    memset(&c, 0, sizeof c);
+    c.n = (uint32_t)ops.size();
+    for (size_t k = 0; k < ops.size(); ++k) c.op[k] = ops[k];
+    for (size_t i = 0; i < chains.size(); ++i)
+        if (memcmp(&chains[i], &c, sizeof c) == 0) return (int)i;
+    if (chains.size() >= (size_t)RT_ILEAF_MAX_CHAINS) return -1;
+    chains.push_back(c);
+    return (int)chains.size() - 1;
+}
+RtChainOp chain_op(uint32_t op, double a, double b, double c) {
+    RtChainOp o;
+    memset(&o, 0, sizeof o);
+    o.a = a; o.b = b; o.c = c; o.op = op & RT_OP_MASK;
+    return o;
+}
+bool ileaf_primitive(uint32_t ref) {
+    const uint32_t t = RT_REF_TYPE(ref);
+    return (t == RT_REF_SPHERE || t == RT_REF_MSPHERE || t == RT_REF_RECT || t == RT_REF_BOX) && RT_REF_INDEX(ref) <= RT_ILEAF_PRIM_MASK;
+}
 RtMeta make_meta(const ObjRec& o, int handle, int parent) {
     RtMeta m;
     m.material = (uint32_t)o.mat; m.parent_inst = parent; m.src_id = (uint32_t)handle; m.pad = 0;
@@ -426,7 +453,24 @@ uint32_t rt_builder::emit(Flat& f, int h, int parent, uint32_t depth, uint32_t& 
         {   // only further instances and then one primitive or medium below: the traversal tests it without entering a frame
             int b = o.child;
             while (objs[b].kind == OBJ_TRANSLATE || objs[b].kind == OBJ_ROTATE_Y) b = objs[b].child;
-            if (objs[b].kind != OBJ_BVH && objs[b].kind != OBJ_LIST) f.insts[me].op |= RT_INST_LEAF;
+            if (objs[b].kind != OBJ_BVH && objs[b].kind != OBJ_LIST) {
+                // ... and where the numbers fit, from the reference alone: this object's step in front of the chain below
+                if (f.ileaf_off == 0 && (ileaf_primitive(c) || RT_REF_TYPE(c) == RT_REF_ILEAF)) {
+                    std::vector<RtChainOp> ops;
+                    ops.push_back(chain_op(in.op, in.a, in.b, in.c));
+                    if (RT_REF_TYPE(c) == RT_REF_ILEAF) {
+                        const RtChain below = f.chains[RT_ILEAF_CHAIN(c)];
+                        for (uint32_t k = 0; k < below.n; ++k) ops.push_back(below.op[k]);
+                    }
+                    const int chain = chain_of(f.chains, ops);
+                    if (chain >= 0) {
+                        need = 0;
+                        return RT_MAKE_ILEAF(chain, RT_REF_TYPE(c) == RT_REF_ILEAF ? RT_ILEAF_PRIM(c) : c);
+                    }
+                }
+                // (over an RT_REF_ILEAF that found no room for the longer chain: an instance like any other, entered and left)
+                if (RT_REF_TYPE(c) != RT_REF_ILEAF) f.insts[me].op |= RT_INST_LEAF;
+            }
         }
         need = std::max(2u, 1u + cneed);
         return RT_MAKE_REF(RT_REF_INST, me);
@@ -444,7 +488,9 @@ uint32_t rt_builder::emit(Flat& f, int h, int parent, uint32_t depth, uint32_t& 
             return RT_REF_NONE;
         }
         uint32_t bneed;
+        ++f.ileaf_off; // (rt_boundary_t walks RtInst records)
         uint32_t bref = emit(f, o.child, parent, depth, bneed);
+        --f.ileaf_off;
         if (bref == RT_REF_NONE) return RT_REF_NONE;
         RtMedium m;
         m.neg_inv_density = o.d[0];
@@ -1017,6 +1063,41 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
                     const Wrapped& w = wrapped[(size_t)obj - objs.size()];
                     int parent = RT_NO_PARENT;
                     uint32_t first = RT_REF_NONE;
+                    {   // Where the numbers fit, all members below the same instances share one set of RtInst records (for the
+                        // way back out: the hit record is rebuilt through the member's parent links) and one chain record,
+                        // and the member's reference names chain and primitive at once.
+                        const ObjKind sk = objs[w.sub].kind;
+                        const size_t next = sk == OBJ_SPHERE ? f.spheres.size() : sk == OBJ_MSPHERE ? f.mspheres.size() : sk == OBJ_BOX ? f.boxes.size()
+                                          : (sk == OBJ_XYRECT || sk == OBJ_XZRECT || sk == OBJ_YZRECT) ? f.rects.size() : (size_t)-1;
+                        if (f.ileaf_off == 0 && next <= (size_t)RT_ILEAF_PRIM_MASK) {
+                            auto it = f.pushed_chains.find(w.chain);
+                            if (it == f.pushed_chains.end()) {
+                                std::vector<RtChainOp> ops;
+                                for (int hh : w.chain) ops.push_back(chain_op(objs[hh].kind == OBJ_TRANSLATE ? RT_OP_TRANSLATE : RT_OP_ROTATE_Y, objs[hh].d[0], objs[hh].d[1], objs[hh].d[2]));
+                                const int chain = chain_of(f.chains, ops);
+                                if (chain >= 0) {
+                                    int up = RT_NO_PARENT;
+                                    for (size_t k = 0; k < w.chain.size(); ++k) {
+                                        const ObjRec& io = objs[w.chain[k]];
+                                        RtInst in;
+                                        in.a = io.d[0]; in.b = io.d[1]; in.c = io.d[2];
+                                        in.op = (io.kind == OBJ_TRANSLATE ? RT_OP_TRANSLATE : RT_OP_ROTATE_Y) | RT_INST_LEAF;
+                                        in.child = RT_REF_NONE; in.parent_inst = up; in.src_id = (uint32_t)w.chain[k];
+                                        f.insts.push_back(in);
+                                        up = (int)f.insts.size() - 1;
+                                    }
+                                    it = f.pushed_chains.emplace(w.chain, std::make_pair(up, chain)).first;
+                                }
+                            }
+                            if (it != f.pushed_chains.end()) {
+                                f.max_chain = std::max(f.max_chain, (uint32_t)w.chain.size());
+                                const uint32_t c = emit(f, w.sub, it->second.first, (uint32_t)w.chain.size(), ln);
+                                if (c == RT_REF_NONE) return (uint32_t)RT_REF_NONE;
+                                ln = 0;
+                                return (uint32_t)RT_MAKE_ILEAF(it->second.second, c);
+                            }
+                        }
+                    }
                     for (size_t k = 0; k < w.chain.size(); ++k) {
                         const ObjRec& io = objs[w.chain[k]];
                         RtInst in;
@@ -1255,6 +1336,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         put_section(blob, hd.perlin_perm, pperm);
         put_section(blob, hd.texels, texels);
         put_section(blob, hd.exact_boxes, f.exact_boxes);
+        put_section(blob, hd.chains, f.chains);
         blob.size = (blob.size + 255u) & ~(size_t)255u;
     };
     BlobOut blob;

@@ -33,6 +33,7 @@ struct DScene {
     const int32_t* perlin_perm;
     const uint8_t* texels;
     const RtExactBox* exact_boxes;
+    const RtChain* chains;
     uint32_t world, world_flat, world_tree;
     uint32_t n_media;
     uint32_t compat; // bit 0: book-correct RotateY back-rotation; bit 1: book-correct XY lens disk
@@ -62,6 +63,33 @@ RT_HD V3 rt_apply_inst_dir(const RtInst& in, V3 d) {
     if ((in.op & RT_OP_MASK) == RT_OP_TRANSLATE) return d;
     const double s = in.a, c = in.b;
     return v3(c * d.x - s * d.z, d.y, s * d.x + c * d.z);
+}
+
+// The ray as the primitive of an RT_REF_ILEAF reference sees it: the chain's Translate / RotateY steps, outermost first
+// (the same arithmetic as rt_apply_inst, read from one shared record instead of a linked RtInst each).
+RT_HD Ray rt_apply_chain_op(const RtChainOp& in, const Ray& r) {
+    Ray o = r;
+    if ((in.op & RT_OP_MASK) == RT_OP_TRANSLATE) {
+        o.o = r.o - v3(in.a, in.b, in.c);
+    } else {
+        const double s = in.a, c = in.b;
+        o.o.x = c * r.o.x - s * r.o.z;
+        o.o.z = s * r.o.x + c * r.o.z;
+        o.d.x = c * r.d.x - s * r.d.z;
+        o.d.z = s * r.d.x + c * r.d.z;
+    }
+    return o;
+}
+RT_HD Ray rt_apply_chain(const DScene& sc, uint32_t chain, Ray r) {
+    const RtChain* ch = sc.chains + chain;
+    const uint32_t n = ch->n;
+    // the first two steps are asked for together (few chains are longer; unused steps of a record are zero-filled)
+    const RtChainOp op0 = ch->op[0], op1 = ch->op[1];
+    if (n > 0u) r = rt_apply_chain_op(op0, r);
+    if (n > 1u) r = rt_apply_chain_op(op1, r);
+#pragma unroll 1
+    for (uint32_t k = 2u; k < n && k < (uint32_t)RT_MAX_CHAIN; ++k) r = rt_apply_chain_op(ch->op[k], r);
+    return r;
 }
 
 // The world ray carried down to the frame below instance `inst` (RT_NO_PARENT = world frame).
@@ -144,10 +172,24 @@ RT_HD void rt_node_boxes_f32(const RtNode& n, const RtSlab& k, float t_min, floa
     const float n1x = k.nx ? n.hi1[0] : n.lo1[0], f1x = k.nx ? n.lo1[0] : n.hi1[0];
     const float n1y = k.ny ? n.hi1[1] : n.lo1[1], f1y = k.ny ? n.lo1[1] : n.hi1[1];
     const float n1z = k.nz ? n.hi1[2] : n.lo1[2], f1z = k.nz ? n.lo1[2] : n.hi1[2];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_NO_PACKED_F32)
+    // the twelve slab distances as six packed operations (v_pk_fma_f32: two f32 fused multiply-adds per instruction, each
+    // rounded as the single one is)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 ixy = {k.ix, k.iy}, izz = {k.iz, k.iz};
+    const f32x2 cnxy = {-k.cnx, -k.cny}, cnzz = {-k.cnz, -k.cnz}, cfxy = {-k.cfx, -k.cfy}, cfzz = {-k.cfz, -k.cfz};
+    const f32x2 a0xy = __builtin_elementwise_fma((f32x2){n0x, n0y}, ixy, cnxy), a1xy = __builtin_elementwise_fma((f32x2){n1x, n1y}, ixy, cnxy);
+    const f32x2 azz = __builtin_elementwise_fma((f32x2){n0z, n1z}, izz, cnzz);
+    const f32x2 b0xy = __builtin_elementwise_fma((f32x2){f0x, f0y}, ixy, cfxy), b1xy = __builtin_elementwise_fma((f32x2){f1x, f1y}, ixy, cfxy);
+    const f32x2 bzz = __builtin_elementwise_fma((f32x2){f0z, f1z}, izz, cfzz);
+    const float a0x = a0xy.x, a0y = a0xy.y, a0z = azz.x, a1x = a1xy.x, a1y = a1xy.y, a1z = azz.y;
+    const float b0x = b0xy.x, b0y = b0xy.y, b0z = bzz.x, b1x = b1xy.x, b1y = b1xy.y, b1z = bzz.y;
+#else
     const float a0x = __builtin_fmaf(n0x, k.ix, -k.cnx), a0y = __builtin_fmaf(n0y, k.iy, -k.cny), a0z = __builtin_fmaf(n0z, k.iz, -k.cnz);
     const float b0x = __builtin_fmaf(f0x, k.ix, -k.cfx), b0y = __builtin_fmaf(f0y, k.iy, -k.cfy), b0z = __builtin_fmaf(f0z, k.iz, -k.cfz);
     const float a1x = __builtin_fmaf(n1x, k.ix, -k.cnx), a1y = __builtin_fmaf(n1y, k.iy, -k.cny), a1z = __builtin_fmaf(n1z, k.iz, -k.cnz);
     const float b1x = __builtin_fmaf(f1x, k.ix, -k.cfx), b1y = __builtin_fmaf(f1y, k.iy, -k.cfy), b1z = __builtin_fmaf(f1z, k.iz, -k.cfz);
+#endif
     e0 = __builtin_fmaxf(__builtin_fmaxf(a0x, a0y), __builtin_fmaxf(a0z, t_min));
     e1 = __builtin_fmaxf(__builtin_fmaxf(a1x, a1y), __builtin_fmaxf(a1z, t_min));
     const float x0 = __builtin_fminf(__builtin_fminf(b0x, b0y), __builtin_fminf(b0z, t_max));
@@ -442,9 +484,22 @@ struct GlobalNodes {
     RT_HD RtNode load(uint32_t index) const { return rt_load_node(nodes + index); }
     RT_HD RtExactBox exact_box(uint32_t k) const { return exact[k]; }
 };
+// A stack may offer prefetch() - the entry that a pop would uncover, asked for before it is known whether this step
+// pops - and node_step(), which ends the step with it: where a stack read has a latency worth hiding behind the node fetch.
+template <class Stack> RT_HD auto rt_stack_prefetch(const Stack& st, int) -> decltype(st.prefetch()) { return st.prefetch(); }
+template <class Stack> RT_HD uint32_t rt_stack_prefetch(const Stack&, long) { return 0u; }
+template <class Stack>
+RT_HD auto rt_stack_node_step(Stack& st, bool both, bool any, uint32_t go, uint32_t keep, uint32_t under, int)
+    -> decltype(st.node_step(both, any, go, keep, under)) { return st.node_step(both, any, go, keep, under); }
+template <class Stack>
+RT_HD uint32_t rt_stack_node_step(Stack& st, bool both, bool any, uint32_t go, uint32_t keep, uint32_t, long) {
+    if (both) st.push(keep);
+    return any ? go : (st.empty() ? (uint32_t)RT_REF_NONE : st.pop());
+}
 // EXACT_NODES = false: for scenes without a node flagged RT_NODE_EXACT (the flag is then not looked at).
 template <bool EXACT_NODES = true, class Stack, class Nodes>
 RT_HD void rt_trav_node_step(const Nodes& nodes, RtTrav& s, Stack& st, double t_min) {
+    const uint32_t under = rt_stack_prefetch(st, 0);
     const RtNode n = nodes.load(RT_REF_INDEX(s.cur));
     RT_VISIT(0u);
     bool h0, h1, swap;
@@ -468,14 +523,10 @@ RT_HD void rt_trav_node_step(const Nodes& nodes, RtTrav& s, Stack& st, double t_
         swap = e1 < e0;
     }
     h1 = h1 && n.c1 != RT_REF_NONE; // (an absent child has the empty box, which a ray without direction would still "hit")
-    if (h0 && h1) {
-        st.push(swap ? n.c0 : n.c1);
-        s.cur = swap ? n.c1 : n.c0;
-    } else if (h0 || h1) {
-        s.cur = h0 ? n.c0 : n.c1;
-    } else {
-        s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop();
-    }
+    // both boxes hit: on with the nearer child, the other is kept for later; one: on with it; none: the next kept one
+    const bool both = h0 && h1;
+    const uint32_t go = both ? (swap ? n.c1 : n.c0) : (h0 ? n.c0 : n.c1);
+    s.cur = rt_stack_node_step(st, both, h0 || h1, go, swap ? n.c0 : n.c1, under, 0);
 }
 template <class Stack, class Nodes>
 RT_HD void rt_trav_descend(const Nodes& nodes, RtTrav& s, Stack& st, double t_min) {
@@ -504,7 +555,16 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
     } else {
         uint32_t leaf = s.cur;
         Ray moved = s.r;
-        if (type == RT_REF_INST) {
+        if (type == RT_REF_ILEAF) leaf = RT_ILEAF_PRIM(s.cur);
+        // Nearly every leaf is a sphere: its record is asked for before the ray is moved, so that the chain's record and
+        // the sphere's are on their way together.
+        const bool sphere = RT_REF_TYPE(leaf) == RT_REF_SPHERE;
+        RtSphere sph;
+        sph.cx = 0.0; sph.cy = 0.0; sph.cz = 0.0; sph.r = 0.0;
+        if (sphere) sph = sc.spheres[RT_REF_INDEX(leaf)];
+        if (type == RT_REF_ILEAF) {
+            moved = rt_apply_chain(sc, RT_ILEAF_CHAIN(s.cur), moved);
+        } else if (type == RT_REF_INST) {
             RtInst in = sc.insts[idx];
             if ((in.op & RT_INST_LEAF) == 0u) { // a subtree in its own frame: enter it, leave through a POP marker
                 st.push(RT_MAKE_REF(RT_REF_POP, idx));
@@ -523,7 +583,13 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
                 in = sc.insts[RT_REF_INDEX(leaf)];
             }
         }
-        rt_test_leaf(sc, leaf, moved, t_min, s.best, xi, skip_media);
+        if (sphere) {
+            double t;
+            RT_VISIT(1u + RT_REF_SPHERE);
+            if (rt_sphere_t(v3(sph.cx, sph.cy, sph.cz), sph.r, moved, t_min, s.best.t, t)) { s.best.t = t; s.best.ref = leaf; s.best.aux = 0u; }
+        } else {
+            rt_test_leaf(sc, leaf, moved, t_min, s.best, xi, skip_media);
+        }
     }
     s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop();
 }
@@ -560,6 +626,11 @@ RT_HD void rt_extend_flat(const DScene& sc, const RayFn& world_ray, double t_min
         uint32_t e = sc.list_entries[li];
         if (e == RT_REF_NONE) break;
         bool moved = false;
+        if (RT_REF_TYPE(e) == RT_REF_ILEAF) {
+            r = rt_apply_chain(sc, RT_ILEAF_CHAIN(e), r);
+            e = RT_ILEAF_PRIM(e);
+            moved = true;
+        }
 #pragma unroll 1
         while (RT_REF_TYPE(e) == RT_REF_INST) {
             const RtInst in = sc.insts[RT_REF_INDEX(e)];

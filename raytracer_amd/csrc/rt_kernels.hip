@@ -95,23 +95,45 @@ __device__ inline LiveSet live_set(const uint32_t* ctr, size_t cap) {
     return l;
 }
 
+// The newest entry is held in a register (`tos`), the older ones in LDS: a pop hands out the register at once and only
+// then asks the LDS for the entry below, which nothing needs before the next pop or push - so the wave does not sit out an
+// LDS round trip in front of the node fetch that follows every pop. Entry j (counted from the bottom) of the ones in LDS is
+// at base[(j + 1) * stride]; base[0] takes the meaningless register contents that the first push writes out.
 struct LdsStack {
-    uint32_t* base; // this lane's column: entry k at base[k * stride], stride = threads per block (conflict-free)
-    uint32_t sp, cap, stride;
+    uint32_t* base; // this lane's column, stride = threads per block (conflict-free)
+    uint32_t top, lim, stride; // top = entries held * stride (an offset: a push or pop is an add, not a multiply); lim = capacity * stride
+    uint32_t tos;
     uint32_t* error_flag;
+    __device__ void init(uint32_t* column, uint32_t cap, uint32_t stride_, uint32_t* flag) { base = column; top = 0u; tos = 0u; lim = cap * stride_; stride = stride_; error_flag = flag; }
+    __device__ void clear() { top = 0u; }
     __device__ void push(uint32_t v) {
-        if (sp < cap) { base[sp * stride] = v; ++sp; }
+        if (top < lim) { base[top] = tos; tos = v; top += stride; }
         else if (error_flag) atomicOr(error_flag, 1u);
     }
-    __device__ uint32_t pop() { --sp; return base[sp * stride]; }
-    __device__ bool empty() const { return sp == 0u; }
+    __device__ uint32_t pop() { const uint32_t v = tos; top -= stride; tos = base[top]; return v; }
+    // What a pop would uncover, asked for before it is known whether one follows (rt_trav_node_step asks together with its
+    // node record, so that one wait covers both). Nothing held, or one entry: the unused word at the bottom.
+    __device__ uint32_t prefetch() const { return base[max((int)(top - stride), 0)]; }
+    // The stack's part of a node step, without branches but for the store: both boxes hit - `keep` is pushed and the lane
+    // goes on with `go`; one box - on with `go`; none - the top entry, or RT_REF_NONE from an empty stack.
+    __device__ uint32_t node_step(bool both, bool any, uint32_t go, uint32_t keep, uint32_t under) {
+        const bool pushing = both && top < lim, popping = !any && top != 0u;
+        if (pushing) base[top] = tos;
+        else if (both && error_flag) atomicOr(error_flag, 1u);
+        const uint32_t cur = any ? go : (popping ? tos : (uint32_t)RT_REF_NONE);
+        tos = pushing ? keep : (popping ? under : tos);
+        top = pushing ? top + stride : (popping ? top - stride : top);
+        return cur;
+    }
+    __device__ bool empty() const { return top == 0u; }
 };
 
 // The first n_cached node records live in LDS, the rest in global memory. A lane fetches a 64-byte record with four
 // 16-byte reads, each lane a different record: through the vector cache that is one tag lookup per lane per read,
 // 256 per wave and node, which is what bounds traversal when the nodes come from global memory. The LDS serves the
-// same reads at its full width. The 16-byte pieces of a record are stored rotated by the record's index so that the
-// lanes of one read spread over all banks.
+// same reads at its full width. The four 16-byte pieces of the records are kept in four arrays of their own (piece p of
+// record i at p * n_cached + i): the lanes of one read, each after a different record, then spread over all banks as
+// their indices do, and the four addresses of a fetch cost one shift-and-add each.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u32x4* LdsU4; // typed as LDS so that reads are ds_read, not flat loads
 // ALL = true: every node of the scene is in LDS. The kernel is then compiled without the global-memory branch, and that
@@ -133,11 +155,11 @@ struct CachedNodes {
         b.lo[0] = p[0]; b.lo[1] = p[1]; b.lo[2] = p[2]; b.hi[0] = p[3]; b.hi[1] = p[4]; b.hi[2] = p[5];
         return b;
     }
-    __device__ static uint32_t place(uint32_t index, uint32_t piece) { return index * 4u + (piece ^ ((index >> 2) & 3u)); }
+    __device__ static uint32_t place(uint32_t index, uint32_t piece, uint32_t n_cached) { return piece * n_cached + index; }
     __device__ RtNode load(uint32_t index) const {
         u32x4 a, b, c, d; // (d as a full 16-byte read too: a narrower one gets merged with the other branch's into a flat load)
         if (ALL || index < n_cached) {
-            a = lds[place(index, 0u)]; b = lds[place(index, 1u)]; c = lds[place(index, 2u)]; d = lds[place(index, 3u)];
+            a = lds[index]; b = (lds + n_cached)[index]; c = (lds + 2u * n_cached)[index]; d = (lds + 3u * n_cached)[index];
         } else {
             const u32x4* g = (const u32x4*)(global + index);
             a = g[0]; b = g[1]; c = g[2]; d = g[3];
@@ -375,16 +397,12 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
     uint32_t& blk_taken = *(uint32_t*)(lds_tree + (size_t)stack_cap * blockDim.x / 4u + (size_t)n_cached * 4u);
     if (threadIdx.x == 0u) blk_taken = 0u;
     LdsStack st;
-    st.base = (uint32_t*)lds_tree + threadIdx.x;
-    st.cap = stack_cap;
-    st.stride = blockDim.x;
-    st.error_flag = qs.error_flag;
-    st.sp = 0u;
+    st.init((uint32_t*)lds_tree + threadIdx.x, stack_cap, blockDim.x, qs.error_flag);
     CachedNodes<ALL_CACHED> nodes;
     {
         uint4* cache = lds_tree + (size_t)stack_cap * blockDim.x / 4u;
         const uint4* src = (const uint4*)sc.nodes;
-        for (uint32_t i = threadIdx.x; i < n_cached * 4u; i += blockDim.x) cache[CachedNodes<ALL_CACHED>::place(i >> 2, i & 3u)] = src[i];
+        for (uint32_t i = threadIdx.x; i < n_cached * 4u; i += blockDim.x) cache[CachedNodes<ALL_CACHED>::place(i >> 2, i & 3u, n_cached)] = src[i];
         nodes.lds = (LdsU4)cache;
         nodes.n_cached = n_cached;
         nodes.global = sc.nodes;
@@ -447,7 +465,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
                     rt_extend_flat(sc, held, t_min, s.best, xi_of(id, path), skip_media);
                     s.slab = rt_slab_of(s.r, sc.node_extent);
                     s.cur = sc.world_tree;
-                    st.sp = 0u;
+                    st.clear();
                     active = true;
                 }
             }
@@ -728,10 +746,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_first_hit(DScene sc, const rt_ray_
                                                         rt_hit* out, uint32_t stack_cap, uint32_t* error_flag) {
     extern __shared__ uint32_t lds_stack[];
     LdsStack st;
-    st.base = lds_stack + threadIdx.x;
-    st.cap = stack_cap;
-    st.stride = RT_BLOCK;
-    st.error_flag = error_flag;
+    st.init(lds_stack + threadIdx.x, stack_cap, RT_BLOCK, error_flag);
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         const rt_ray_d q = rays[i];
         QueryRay ray_of;
@@ -739,7 +754,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_first_hit(DScene sc, const rt_ray_
         const Ray r = ray_of();
         ArrayXi xi;
         xi.row = xi_rows ? xi_rows + (size_t)i * sc.n_media : nullptr;
-        st.sp = 0u;
+        st.clear();
         const RtHitLite h = rt_extend(sc, ray_of, q.tmin, q.tmax, st, xi, xi_rows == nullptr);
         out[i] = full_hit_record(sc, r, q.tmax, h);
     }
@@ -836,10 +851,10 @@ int parse_header(rt_context* ctx, const RtBlobHeader& h, size_t nbytes) {
     if (h.stack_need > RT_STACK_CAP) return ctx_fail(ctx, RT_ERR_UNSUPPORTED, "blob: traversal stack need exceeds capacity");
     const RtSection* secs[] = {&h.nodes, &h.spheres, &h.sphere_meta, &h.mspheres, &h.msphere_meta, &h.rects, &h.rect_meta,
                                &h.boxes, &h.box_meta, &h.media, &h.insts, &h.list_entries, &h.materials, &h.textures,
-                               &h.perlin_vec, &h.perlin_perm, &h.texels, &h.exact_boxes};
+                               &h.perlin_vec, &h.perlin_perm, &h.texels, &h.exact_boxes, &h.chains};
     const size_t elem[] = {sizeof(RtNode), sizeof(RtSphere), sizeof(RtMeta), sizeof(RtMSphere), sizeof(RtMeta), sizeof(RtRect),
                            sizeof(RtMeta), sizeof(RtBox), sizeof(RtMeta), sizeof(RtMedium), sizeof(RtInst), 4, sizeof(RtMaterial),
-                           sizeof(RtTexture), 8, 4, 1, sizeof(RtExactBox)};
+                           sizeof(RtTexture), 8, 4, 1, sizeof(RtExactBox), sizeof(RtChain)};
     for (size_t i = 0; i < sizeof(secs) / sizeof(secs[0]); ++i)
         if (secs[i]->offset > nbytes || secs[i]->count * elem[i] > nbytes - secs[i]->offset)
             return ctx_fail(ctx, RT_ERR_INVALID, "blob: section out of range");
@@ -868,6 +883,7 @@ void make_view(rt_scene* s) {
     v.perlin_perm = (const int32_t*)(b + h.perlin_perm.offset);
     v.texels = (const uint8_t*)(b + h.texels.offset);
     v.exact_boxes = (const RtExactBox*)(b + h.exact_boxes.offset);
+    v.chains = (const RtChain*)(b + h.chains.offset);
     v.world = RT_REF_NONE;
     v.world_flat = h.world_flat_any_time; // rays of any time (rt_trace_first_hit); a render narrows it, see rt_render_accumulate
     v.world_tree = h.world_tree;

@@ -10,7 +10,7 @@
 #include <stdint.h>
 
 #define RT_BLOB_MAGIC 0x31425452u /* "RTB1" little endian */
-#define RT_BLOB_VERSION 13u
+#define RT_BLOB_VERSION 14u
 
 // ---- tagged references -------------------------------------------------------------------------
 enum RtRefType : uint32_t {
@@ -23,9 +23,13 @@ enum RtRefType : uint32_t {
     RT_REF_MEDIUM = 6,   // ConstantMedium     (raytracer/src/constant_medium.rs:8-12)
     RT_REF_INST = 7,     // Translate / RotateY (raytracer/src/hittable.rs:54-57,95-101)
     RT_REF_LIST = 8,     // HittableList: index of its first entry in the NONE-terminated entry array
-    RT_REF_POP = 9       // traversal-internal marker: leave instance `index`
+    RT_REF_POP = 9,      // traversal-internal marker: leave instance `index`
+    RT_REF_ILEAF = 10    // one Sphere / MovingSphere / rect / _Box seen through Translate / RotateY objects, everything in the
+                         // ref itself: aux = the primitive's type - RT_REF_SPHERE, index = chain[25:20] | primitive[19:0]
+                         // (RtChain record, record of the primitive's own table). A traversal needs no dependent reads to
+                         // test it. The compiler emits it wherever chain and primitive numbers fit, RT_REF_INST otherwise.
 };
-// layout: type[31:28] | aux[27:26] (unused, zero) | index[25:0]
+// layout: type[31:28] | aux[27:26] (zero but in RT_REF_ILEAF) | index[25:0]
 #define RT_REF_SHIFT 28u
 #define RT_REF_INDEX_MASK 0x03FFFFFFu
 #define RT_REF_AUX_SHIFT 26u
@@ -34,6 +38,14 @@ enum RtRefType : uint32_t {
 #define RT_REF_INDEX(ref) ((uint32_t)(ref)&RT_REF_INDEX_MASK)
 #define RT_REF_AUX(ref) (((uint32_t)(ref) >> RT_REF_AUX_SHIFT) & 3u)
 #define RT_REF_STRIP_AUX(ref) ((uint32_t)(ref) & ~(3u << RT_REF_AUX_SHIFT))
+
+#define RT_ILEAF_CHAIN_SHIFT 20u
+#define RT_ILEAF_PRIM_MASK 0xFFFFFu
+#define RT_ILEAF_MAX_CHAINS 64u
+#define RT_MAKE_ILEAF(chain, prim_ref) \
+    ((((uint32_t)RT_REF_ILEAF) << RT_REF_SHIFT) | ((RT_REF_TYPE(prim_ref) - (uint32_t)RT_REF_SPHERE) << RT_REF_AUX_SHIFT) | ((uint32_t)(chain) << RT_ILEAF_CHAIN_SHIFT) | RT_REF_INDEX(prim_ref))
+#define RT_ILEAF_PRIM(ref) RT_MAKE_REF((uint32_t)RT_REF_SPHERE + RT_REF_AUX(ref), (uint32_t)(ref)&RT_ILEAF_PRIM_MASK)
+#define RT_ILEAF_CHAIN(ref) (RT_REF_INDEX(ref) >> RT_ILEAF_CHAIN_SHIFT)
 
 #define RT_NO_PARENT (-1)
 #define RT_MAX_CHAIN 4   /* deepest Translate/RotateY nesting above any primitive */
@@ -91,6 +103,11 @@ struct RtInst {
     uint32_t src_id;
 };
 
+// The Translate / RotateY objects above an RT_REF_ILEAF primitive, outermost first, by value: what RtInst records hold,
+// without their links, so that every primitive under the same objects shares one record.
+struct RtChainOp { double a, b, c; uint32_t op; uint32_t pad; };
+struct RtChain { uint32_t n; uint32_t pad; RtChainOp op[RT_MAX_CHAIN]; };
+
 enum RtMaterialType : uint32_t {
     RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2, RT_MAT_DIFFUSE_LIGHT = 3,
     RT_MAT_ISOTROPIC = 4, RT_MAT_COUNT = 5
@@ -141,7 +158,7 @@ struct RtBlobHeader {
     double node_extent;        // largest finite |coordinate| of any node box (0 without nodes): scales the error bound of the f32 box test
     uint64_t n_exact_nodes;    // nodes flagged RT_NODE_EXACT
     RtSection nodes, spheres, sphere_meta, mspheres, msphere_meta, rects, rect_meta, boxes, box_meta,
-        media, insts, list_entries, materials, textures, perlin_vec, perlin_perm, texels, exact_boxes;
+        media, insts, list_entries, materials, textures, perlin_vec, perlin_perm, texels, exact_boxes, chains;
     // A world tree left for the device to build (RT_BLOB_FLAG_DEVICE_TREE). The compiler has put its leaves, in the order
     // it met them, under a balanced stand-in tree: a node over leaves [s, e) has child 0 over [s, m) and child 1 over
     // [m, e), m = s + (e - s) / 2, down to single leaves. The stand-in is valid (every box bounds what is below it) but

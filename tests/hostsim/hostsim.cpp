@@ -64,6 +64,7 @@ bool view_of(const void* blob, size_t nbytes, DScene& v, RtBlobHeader& h) {
     v.perlin_perm = (const int32_t*)(b + h.perlin_perm.offset);
     v.texels = (const uint8_t*)(b + h.texels.offset);
     v.exact_boxes = (const RtExactBox*)(b + h.exact_boxes.offset);
+    v.chains = (const RtChain*)(b + h.chains.offset);
     v.world = RT_REF_NONE;
     v.world_flat = h.world_flat_any_time;
     v.world_tree = h.world_tree;

@@ -86,9 +86,9 @@ HEADER = struct.Struct("<IIQIIIIIIIIdddddQ")  # magic, version, total, world_fla
 
 def header(blob):
     magic, version, total, world, world_flat, world_tree, n_media, stack_need, max_chain, flags, n_objects, shutter0, shutter1, valid0, valid1, node_extent, n_exact_nodes = HEADER.unpack_from(blob, 0)
-    secs = np.frombuffer(blob, dtype="<u8", count=17 * 2, offset=HEADER.size).reshape(17, 2)
+    secs = np.frombuffer(blob, dtype="<u8", count=19 * 2, offset=HEADER.size).reshape(19, 2)
     names = ["nodes", "spheres", "sphere_meta", "mspheres", "msphere_meta", "rects", "rect_meta", "boxes", "box_meta", "media",
-             "insts", "list_entries", "materials", "textures", "perlin_vec", "perlin_perm", "texels"]
+             "insts", "list_entries", "materials", "textures", "perlin_vec", "perlin_perm", "texels", "exact_boxes", "chains"]
     return dict(magic=magic, version=version, total=total, world_flat_any_time=world, world_flat=world_flat, world_tree=world_tree, n_media=n_media, stack_need=stack_need,
                 shutter=(shutter0, shutter1), valid=(valid0, valid1),
                 max_chain=max_chain, flags=flags, n_objects=n_objects, sections={n: tuple(map(int, s)) for n, s in zip(names, secs)})
@@ -119,14 +119,15 @@ def test_blob_layout_of_the_book2_final_scene():
     s = h["sections"]
     # The world list holds 11 entries (main.rs:576-688). One is tested by every lane in lock step: the r=5000 medium that
     # contains the whole scene. The BvhNode of 400 boxes is dissolved, and so is the instanced cluster - Translate over
-    # RotateY over a BvhNode of 1000 spheres becomes 1000 spheres each under its own copy of the two instance records,
+    # RotateY over a BvhNode of 1000 spheres becomes 1000 spheres that share one chain record (the two steps by value)
+    # and one pair of instance records (for the way back out), each named together with the chain by its reference and
     # bounded in the world's frame: one tree of 400 + 8 + 1000 leaves = 1407 nodes, no frame change while walking it.
     # The moving sphere sits in the tree under the bound of its own time interval [0, 1] and, for rays of other times,
     # on the second lock-step list as well.
     assert s["nodes"][1] == 1407
     assert s["boxes"][1] == 400 and s["mspheres"][1] == 1 and s["rects"][1] == 1
     assert s["spheres"][1] == 1000 + 5 + 2            # + the two medium boundaries (one is the shared r=70 sphere again)
-    assert s["media"][1] == 2 == h["n_media"] and s["insts"][1] == 2000 and h["max_chain"] == 2
+    assert s["media"][1] == 2 == h["n_media"] and s["insts"][1] == 2 and s["chains"][1] == 1 and h["max_chain"] == 2
     assert s["texels"][1] == 1024 * 512 * 3 and s["perlin_vec"][1] == 768 and s["perlin_perm"][1] == 768
     assert all(off % 256 == 0 for off, _ in s.values())
     assert 2 <= h["stack_need"] <= 40
@@ -147,10 +148,11 @@ def test_blob_layout_of_the_book2_final_scene():
     # everything in the tree: ground boxes x, z in [-1000, 1000), the light at y = 554, the cluster up to z < 620
     assert np.all(lo <= [-1000, 0, -1000]) and np.all(lo > [-1001, -1, -1001])
     assert np.all(hi >= [1000 - 1, 554, 1000 - 1]) and np.all(hi < [1001, 600, 1001])
-    # the cluster's spheres hang under the tree as Translate records flagged as leaves (op = 0 | 0x100), each with the
-    # world-space bound of its sphere: r=10, centres in [0,165)^3 rotated 15 degrees about y and moved by (-100,270,395)
-    found = [(n["lo0"], n["hi0"]) for n in nodes if n["c0"] >> 28 == 7] + [(n["lo1"], n["hi1"]) for n in nodes if n["c1"] >> 28 == 7]
-    assert len(found) == 1000
+    # the cluster's spheres hang under the tree as references of type 10 (aux 0 = sphere, chain 0, sphere number), each
+    # with the world-space bound of its sphere: r=10, centres in [0,165)^3 rotated 15 degrees about y and moved by (-100,270,395)
+    found = [(n["lo0"], n["hi0"], n["c0"]) for n in nodes if n["c0"] >> 28 == 10] + [(n["lo1"], n["hi1"], n["c1"]) for n in nodes if n["c1"] >> 28 == 10]
+    assert len(found) == 1000 and not any(n["c0"] >> 28 == 7 or n["c1"] >> 28 == 7 for n in nodes)
+    assert all((int(f[2]) >> 20) & 0xFF == 0 for f in found) and len({int(f[2]) & 0xFFFFF for f in found}) == 1000
     wlo = np.min([f[0] for f in found], axis=0)
     whi = np.max([f[1] for f in found], axis=0)
     assert np.all(wlo < [-100, 265, 350]) and np.all(whi > [60, 430, 540])
@@ -158,11 +160,15 @@ def test_blob_layout_of_the_book2_final_scene():
     assert all(np.all(np.abs((f[1] - f[0]) - 20.0) < 0.01) for f in found)
     INST = np.dtype([("a", "<f8"), ("b", "<f8"), ("c", "<f8"), ("op", "<u4"), ("child", "<u4"), ("parent", "<i4"), ("src", "<u4")])
     insts = np.frombuffer(blob, dtype=INST, count=s["insts"][1], offset=s["insts"][0])
-    assert set(insts["op"].tolist()) == {0x100, 0x101}
-    outer = insts[insts["parent"] < 0]
-    assert len(outer) == 1000 and np.all(outer["op"] == 0x100) and np.all(outer["child"] >> 28 == 7)
-    inner = insts[insts["parent"] >= 0]
-    assert np.all(inner["op"] == 0x101) and np.all(inner["child"] >> 28 == 2)
+    assert insts["op"].tolist() == [0x100, 0x101] and insts["parent"].tolist() == [-1, 0]
+    meta = np.frombuffer(blob, dtype=np.dtype([("material", "<u4"), ("parent", "<i4"), ("src", "<u4"), ("pad", "<u4")]), count=s["sphere_meta"][1], offset=s["sphere_meta"][0])
+    assert sorted(int(meta["parent"][int(f[2]) & 0xFFFFF]) for f in found) == [1] * 1000
+    CHAIN = np.dtype([("n", "<u4"), ("pad", "<u4"), ("op", np.dtype([("a", "<f8"), ("b", "<f8"), ("c", "<f8"), ("op", "<u4"), ("pad", "<u4")]), 4)])
+    assert CHAIN.itemsize == 136
+    chain = np.frombuffer(blob, dtype=CHAIN, count=1, offset=s["chains"][0])[0]
+    assert chain["n"] == 2 and chain["op"]["op"].tolist() == [0, 1, 0, 0]
+    assert chain["op"][0][["a", "b", "c"]].tolist() == (-100.0, 270.0, 395.0) == insts[0][["a", "b", "c"]].tolist()
+    assert chain["op"][1]["a"] == insts[1]["a"] == np.sin(np.radians(15.0)) or abs(chain["op"][1]["a"] - np.sin(np.radians(15.0))) < 1e-15
 
 
 def test_cornell_replays_the_reference_order():

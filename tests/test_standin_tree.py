@@ -11,7 +11,7 @@ import util
 from raytracer_amd import api
 
 TAIL = struct.Struct("<IIIII")   # device_tree_root, _leaves, _leaf_need, _need_other, _need_add
-TAIL_OFFSET = 384                # behind the 18 section records of RtBlobHeader
+TAIL_OFFSET = 400                # behind the 19 section records of RtBlobHeader
 NODE = 1
 
 
