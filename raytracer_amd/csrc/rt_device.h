@@ -83,12 +83,8 @@ RT_HD Ray rt_apply_chain_op(const RtChainOp& in, const Ray& r) {
 RT_HD Ray rt_apply_chain(const DScene& sc, uint32_t chain, Ray r) {
     const RtChain* ch = sc.chains + chain;
     const uint32_t n = ch->n;
-    // the first two steps are asked for together (few chains are longer; unused steps of a record are zero-filled)
-    const RtChainOp op0 = ch->op[0], op1 = ch->op[1];
-    if (n > 0u) r = rt_apply_chain_op(op0, r);
-    if (n > 1u) r = rt_apply_chain_op(op1, r);
 #pragma unroll 1
-    for (uint32_t k = 2u; k < n && k < (uint32_t)RT_MAX_CHAIN; ++k) r = rt_apply_chain_op(ch->op[k], r);
+    for (uint32_t k = 0u; k < n && k < (uint32_t)RT_MAX_CHAIN; ++k) r = rt_apply_chain_op(ch->op[k], r);
     return r;
 }
 
@@ -172,24 +168,10 @@ RT_HD void rt_node_boxes_f32(const RtNode& n, const RtSlab& k, float t_min, floa
     const float n1x = k.nx ? n.hi1[0] : n.lo1[0], f1x = k.nx ? n.lo1[0] : n.hi1[0];
     const float n1y = k.ny ? n.hi1[1] : n.lo1[1], f1y = k.ny ? n.lo1[1] : n.hi1[1];
     const float n1z = k.nz ? n.hi1[2] : n.lo1[2], f1z = k.nz ? n.lo1[2] : n.hi1[2];
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_NO_PACKED_F32)
-    // the twelve slab distances as six packed operations (v_pk_fma_f32: two f32 fused multiply-adds per instruction, each
-    // rounded as the single one is)
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 ixy = {k.ix, k.iy}, izz = {k.iz, k.iz};
-    const f32x2 cnxy = {-k.cnx, -k.cny}, cnzz = {-k.cnz, -k.cnz}, cfxy = {-k.cfx, -k.cfy}, cfzz = {-k.cfz, -k.cfz};
-    const f32x2 a0xy = __builtin_elementwise_fma((f32x2){n0x, n0y}, ixy, cnxy), a1xy = __builtin_elementwise_fma((f32x2){n1x, n1y}, ixy, cnxy);
-    const f32x2 azz = __builtin_elementwise_fma((f32x2){n0z, n1z}, izz, cnzz);
-    const f32x2 b0xy = __builtin_elementwise_fma((f32x2){f0x, f0y}, ixy, cfxy), b1xy = __builtin_elementwise_fma((f32x2){f1x, f1y}, ixy, cfxy);
-    const f32x2 bzz = __builtin_elementwise_fma((f32x2){f0z, f1z}, izz, cfzz);
-    const float a0x = a0xy.x, a0y = a0xy.y, a0z = azz.x, a1x = a1xy.x, a1y = a1xy.y, a1z = azz.y;
-    const float b0x = b0xy.x, b0y = b0xy.y, b0z = bzz.x, b1x = b1xy.x, b1y = b1xy.y, b1z = bzz.y;
-#else
     const float a0x = __builtin_fmaf(n0x, k.ix, -k.cnx), a0y = __builtin_fmaf(n0y, k.iy, -k.cny), a0z = __builtin_fmaf(n0z, k.iz, -k.cnz);
     const float b0x = __builtin_fmaf(f0x, k.ix, -k.cfx), b0y = __builtin_fmaf(f0y, k.iy, -k.cfy), b0z = __builtin_fmaf(f0z, k.iz, -k.cfz);
     const float a1x = __builtin_fmaf(n1x, k.ix, -k.cnx), a1y = __builtin_fmaf(n1y, k.iy, -k.cny), a1z = __builtin_fmaf(n1z, k.iz, -k.cnz);
     const float b1x = __builtin_fmaf(f1x, k.ix, -k.cfx), b1y = __builtin_fmaf(f1y, k.iy, -k.cfy), b1z = __builtin_fmaf(f1z, k.iz, -k.cfz);
-#endif
     e0 = __builtin_fmaxf(__builtin_fmaxf(a0x, a0y), __builtin_fmaxf(a0z, t_min));
     e1 = __builtin_fmaxf(__builtin_fmaxf(a1x, a1y), __builtin_fmaxf(a1z, t_min));
     const float x0 = __builtin_fminf(__builtin_fminf(b0x, b0y), __builtin_fminf(b0z, t_max));
@@ -556,12 +538,6 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
         uint32_t leaf = s.cur;
         Ray moved = s.r;
         if (type == RT_REF_ILEAF) leaf = RT_ILEAF_PRIM(s.cur);
-        // Nearly every leaf is a sphere: its record is asked for before the ray is moved, so that the chain's record and
-        // the sphere's are on their way together.
-        const bool sphere = RT_REF_TYPE(leaf) == RT_REF_SPHERE;
-        RtSphere sph;
-        sph.cx = 0.0; sph.cy = 0.0; sph.cz = 0.0; sph.r = 0.0;
-        if (sphere) sph = sc.spheres[RT_REF_INDEX(leaf)];
         if (type == RT_REF_ILEAF) {
             moved = rt_apply_chain(sc, RT_ILEAF_CHAIN(s.cur), moved);
         } else if (type == RT_REF_INST) {
@@ -583,13 +559,7 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
                 in = sc.insts[RT_REF_INDEX(leaf)];
             }
         }
-        if (sphere) {
-            double t;
-            RT_VISIT(1u + RT_REF_SPHERE);
-            if (rt_sphere_t(v3(sph.cx, sph.cy, sph.cz), sph.r, moved, t_min, s.best.t, t)) { s.best.t = t; s.best.ref = leaf; s.best.aux = 0u; }
-        } else {
-            rt_test_leaf(sc, leaf, moved, t_min, s.best, xi, skip_media);
-        }
+        rt_test_leaf(sc, leaf, moved, t_min, s.best, xi, skip_media);
     }
     s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop();
 }
