@@ -168,6 +168,42 @@ def test_random_scene_graphs(seed):
         assert (want["prim_id"] != MISS).mean() > 0.01
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+def test_instanced_leaves_in_every_encoding(variant):
+    """A primitive under Translate / RotateY objects is named by chain and primitive number in the reference itself where
+    both fit, by linked instance records where they do not: first hits, hit records and renders agree with the oracle
+    in both forms, in lists and in trees, with the compiler's trees, the reference's, and the device stand-in."""
+    for flags in (0, 2, 8):
+        b, world = util.many_instances_scene(variant, flags)
+        blob, desc = b.compile(world), b.describe(world)
+        refs = np.frombuffer(blob, dtype="<u4")
+        h = __import__("test_abi_and_compiler").header(blob)
+        nodes = np.frombuffer(blob, dtype="<u4", count=h["sections"]["nodes"][1] * 16, offset=h["sections"]["nodes"][0]).reshape(-1, 16)
+        entries = np.frombuffer(blob, dtype="<u4", count=h["sections"]["list_entries"][1], offset=h["sections"]["list_entries"][0])
+        kinds = set((np.concatenate([nodes[:, 12], nodes[:, 13], entries]) >> 28).tolist())
+        assert 10 in kinds and h["sections"]["chains"][1] >= 1
+        if variant == 0:
+            assert 7 in kinds and h["sections"]["chains"][1] == 64   # the table is full: the rest is linked records
+        osc = ck.OracleScene(desc, share_bvh_axes=True)
+        rng = np.random.default_rng(500 + variant)
+        rays = util.random_rays(rng, 4000, any_time=False)
+        xi = rng.random((len(rays), osc.n_media)) if osc.n_media else None
+        want = osc.trace_first_hit(rays, xi)
+        got, _ = ck.hostsim_trace_first_hit(blob, rays, xi)
+        rep = util.first_hit_report(got, want)
+        assert rep["prim_match"] == 1.0 and rep["t_bit_equal"] == 1.0, (variant, flags, rep)
+        hit = rep["both_hit"]
+        for f in ("px", "py", "pz", "nx", "ny", "nz"):   # the hit record is rebuilt through the member's instance records
+            assert util.abs_err(got[f][hit], want[f][hit]).max() < 1e-12, (variant, flags, f)
+        assert np.array_equal(got["flags"][hit], want["flags"][hit]) and np.array_equal(got["material_id"][hit], want["material_id"][hit])
+        assert (want["prim_id"] != MISS).mean() > 0.1
+    cam = api.make_camera((0, 3, -24), (0, 0, 0), (0, 1, 0), 40.0, 4 / 3, 0.1, 20.0, 0.0, 1.0)
+    p = api.make_params(20, 15, max_depth=10, background=(0.7, 0.8, 1.0), seed=91 + variant)
+    a, _ = ck.hostsim_render(blob, cam, p, 2)
+    w, _ = osc.render(cam, p, 2, threads=4)
+    assert float((util.rel_err(a, w) > 1e-9).mean()) == 0.0 and a.mean() > 0.0
+
+
 def test_ray_times_outside_the_interval_a_bvh_over_moving_spheres_was_built_for():
     """random_scene keeps ~390 moving spheres in BvhNode::new_(.., 0.0, 1.0): rebuilt by the compiler, that tree is right
     for ray times in [0, 1] only and says so; compiled with flag 4 it is replayed in the reference's form for any time."""

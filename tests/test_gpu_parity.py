@@ -138,6 +138,43 @@ def test_random_scene_graphs_on_the_gpu(gpu_ctx, seed):
         scene.close()
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+def test_instanced_leaves_in_every_encoding_on_the_gpu(gpu_ctx, variant):
+    """Primitives under Translate / RotateY named by chain and primitive number, and - past the 64 chains a reference can
+    name - by linked instance records (see the CPU test of the same name): both kernels against the oracle, host-built,
+    reference-shaped and device-built trees, and a render."""
+    for flags in (0, 2, api.FLAG_DEVICE_TREE):
+        b, world = util.many_instances_scene(variant, flags)
+        blob, desc = b.compile(world), b.describe(world)
+        osc = ck.OracleScene(desc, share_bvh_axes=True)
+        scene = gpu_ctx.upload(blob)
+        if flags == api.FLAG_DEVICE_TREE:
+            try:
+                gpu_ctx.build_tree(scene)
+            except api.RtError as e:   # (a world whose entries must keep their order leaves no tree to the device)
+                assert e.code == -1 and variant == 0
+        rng = np.random.default_rng(500 + variant)
+        rays = util.random_rays(rng, 20000, any_time=False)
+        xi = rng.random((len(rays), osc.n_media)) if osc.n_media else None
+        want = osc.trace_first_hit(rays, xi)
+        lane = gpu_ctx.trace_first_hit(scene, rays, xi)
+        rep = util.first_hit_report(lane, want)
+        assert rep["prim_match"] >= 0.9999 and rep["t_rel_max"] <= 1e-5 and rep["t_bit_equal"] >= 0.98, (variant, flags, rep)
+        hit = rep["both_hit"]
+        for f in ("px", "py", "pz", "nx", "ny", "nz"):
+            assert util.abs_err(lane[f][hit], want[f][hit]).max() < 1e-9, (variant, flags, f)
+        assert np.array_equal(lane["flags"][hit], want["flags"][hit])
+        for kernel in (0, 3):
+            assert gpu_ctx.trace_first_hit(scene, rays, xi, wavefront=kernel).tobytes() == lane.tobytes(), (variant, flags, kernel)
+        if flags == 0:
+            cam = api.make_camera((0, 3, -24), (0, 0, 0), (0, 1, 0), 40.0, 4 / 3, 0.1, 20.0, 0.0, 1.0)
+            p = api.make_params(48, 36, max_depth=10, background=(0.7, 0.8, 1.0), seed=91 + variant, spp_per_pass=3)
+            got = gpu_ctx.render(scene, cam, p, 4)
+            w, _ = osc.render(cam, p, 4)
+            assert float((util.rel_err(got, w) > 1e-9).mean()) <= 0.005 and abs(got.mean() / w.mean() - 1.0) <= 1e-3
+        scene.close()
+
+
 def test_inside_out_spheres_on_the_gpu(gpu_ctx):
     """Spheres of negative radius: hit like any sphere in a list, cut off under a BvhNode by whatever its box unions leave
     out (sphere.rs:66-72, bvh.rs:55-60) - the trees the product replays box by box."""

@@ -264,6 +264,44 @@ def hostile_scene_graph(seed, flags=0):
     return b, b.list(top)
 
 
+def many_instances_scene(variant, flags=0):
+    """Scenes made of primitives under Translate / RotateY objects, to cover every way the compiler names such a leaf:
+    0: 90 spheres and boxes each under its OWN chain of one to three instances (more distinct chains than the 64 a
+       reference can name: the first get chain records, the rest fall back to linked instance records - some with the
+       inner part of their chain named and the outer part not), in a world list and under a BvhNode;
+    1: Translate over RotateY over a BvhNode of 300 spheres and boxes (members pushed down to the leaves, one shared chain)
+       beside RotateY over a list of rects, plus a medium whose boundary is an instanced box.
+    -> (builder, world)"""
+    rng = np.random.default_rng(4242 + variant)
+    b = api.Builder(seed=SCENE_SEED + 77 + variant, flags=flags)
+    mats = [b.lambertian_color(0.6, 0.5, 0.4), b.metal(0.8, 0.8, 0.7, 0.1), b.dielectric(1.5)]
+
+    def prim(spread):
+        c = rng.uniform(-spread, spread, 3)
+        m = mats[int(rng.integers(len(mats)))]
+        k = int(rng.integers(4))
+        if k == 0:
+            return b.box(tuple(c), tuple(c + rng.uniform(0.4, 1.5, 3)), m)
+        if k == 1:
+            return b.xy_rect(float(c[0]), float(c[0] + 1.2), float(c[1]), float(c[1] + 0.9), float(c[2]), m)
+        return b.sphere(tuple(c), float(rng.uniform(0.3, 0.9)), m)
+
+    if variant == 0:
+        members = []
+        for k in range(90):
+            h = prim(7.0)
+            for _ in range(1 + k % 3):
+                h = b.translate(h, tuple(rng.uniform(-2, 2, 3))) if rng.random() < 0.5 else b.rotate_y(h, float(rng.uniform(-60, 60)))
+            members.append(h)
+        world = b.list(members[:30] + [b.bvh(b.list(members[30:]), 0.0, 1.0)])
+    else:
+        cluster = b.translate(b.rotate_y(b.bvh(b.list([prim(6.0) for _ in range(300)]), 0.0, 1.0), 15.0), (-1.0, 2.0, 3.0))
+        rects = b.rotate_y(b.list([b.xz_rect(-9.0, 9.0, -9.0, 9.0, -8.0, mats[0]), b.yz_rect(-9.0, 9.0, -9.0, 9.0, 9.5, mats[1])]), 10.0)
+        fog = b.constant_medium(b.translate(b.rotate_y(b.box((-3.0, -3.0, -3.0), (3.0, 3.0, 3.0), mats[0]), 30.0), (8.0, 0.0, 0.0)), 0.3, 0.9, 0.9, 0.9)
+        world = b.list([cluster, rects, fog])
+    return b, world
+
+
 def same_first_hits(a, b, t_rel=0.0):
     """Two sets of first-hit records of the same rays, where t may be NaN, negative or infinite: the same primitive and
     the same t (to the bit for t_rel = 0, NaN equal to NaN) -> fraction of rays that agree."""
