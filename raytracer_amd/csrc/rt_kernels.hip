@@ -199,6 +199,11 @@ struct QueryBatch {
     uint32_t n;
 };
 
+// The lanes of the wave for which `p` holds, as a mask. (__ballot takes an int: the compiler first turns the condition,
+// which it already holds as a lane mask, into a 0/1 per lane and compares that with 0 again - two vector instructions
+// per ballot, which the loop heads of k_extend_tree feel.)
+__device__ inline unsigned long long rt_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // Hands every thread with `take` set a distinct position counted from *counter: ONE atomic per workgroup (a single
 // counter word takes only ~90 atomics per microsecond chip-wide, so per-wave appends of millions of waves would
 // serialise on it). Every thread of the block must call it.
@@ -436,7 +441,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
 #endif
 #pragma unroll 1
     for (;;) {
-        const unsigned long long idle = __ballot(!active);
+        const unsigned long long idle = rt_ballot(!active);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         if (n_idle == 64u && exhausted) break;
         RT_PHASE_ADD(0, 1); RT_PHASE_ADD(7, 64u - n_idle);
@@ -472,24 +477,28 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             if (index_of(v0 + n_idle) >= n) exhausted = true; // whoever draws next would find nothing
             RT_PHASE_CLOCK(c_round2);
             RT_PHASE_SPAN(41, c_round1, c_round2);
-            if (__ballot(active) == 0ull && exhausted) break;
+            if (rt_ballot(active) == 0ull && exhausted) break;
         }
         RT_PHASE_CLOCK(c_nodes0);
         // Leaves are tested once this many lanes wait at one: leaf_pct per cent of the lanes that hold a ray at all. (A fixed
         // number - 30 of 64 - is too many just before a refill, when 30 lanes are most of those left, and the few still
         // at a node then step alone; in proportion: -3.4 % kernel time on the Book-2 scene, -7 % on cornell_smoke.)
-        const uint32_t leaf_now = max(4u, (uint32_t)__popcll(__ballot(active)) * leaf_pct / 100u);
+        const uint32_t n_active = (uint32_t)__popcll(rt_ballot(active));
+        const uint32_t leaf_now = max(4u, n_active * leaf_pct / 100u);
         // ---- box tests: every lane that holds a node steps ----
+        // (A lane without a ray holds RT_REF_NONE, so "at a node" needs no look at `active`: the comparison's own lane mask
+        // is the ballot, and the lanes that wait are counted from it by scalar instructions alone.)
 #pragma unroll 1
         for (;;) {
-            const bool at_node = active && RT_REF_TYPE(s.cur) == RT_REF_NODE;
-            if (__ballot(at_node) == 0ull) break;
-            if ((uint32_t)__popcll(__ballot(active && !at_node)) >= leaf_now) break;
-            RT_PHASE_ADD(3, 1); RT_PHASE_ADD(4, __popcll(__ballot(at_node)));
+            const bool at_node = RT_REF_TYPE(s.cur) == RT_REF_NODE;
+            const unsigned long long m_node = rt_ballot(at_node);
+            if (m_node == 0ull) break;
+            if (n_active - (uint32_t)__popcll(m_node) >= leaf_now) break;
+            RT_PHASE_ADD(3, 1); RT_PHASE_ADD(4, __popcll(m_node));
             if (at_node) rt_trav_node_step<EXACT_NODES>(nodes, s, st, t_min);
             // a second step before the next look at the wave: the two ballots above cost a sixth of a step (-3.6 % kernel
             // time; a third and fourth step bring nothing more, measured again with the relative leaf threshold)
-            if (active && RT_REF_TYPE(s.cur) == RT_REF_NODE) rt_trav_node_step<EXACT_NODES>(nodes, s, st, t_min);
+            if (RT_REF_TYPE(s.cur) == RT_REF_NODE) rt_trav_node_step<EXACT_NODES>(nodes, s, st, t_min);
         }
         RT_PHASE_CLOCK(c_nodes1);
         RT_PHASE_SPAN(42, c_nodes0, c_nodes1);
@@ -497,10 +506,10 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
 #ifdef RT_PHASE_STATS
         {
             const bool v = active && s.cur != RT_REF_NONE && RT_REF_TYPE(s.cur) != RT_REF_NODE;
-            const unsigned long long any = __ballot(v);
+            const unsigned long long any = rt_ballot(v);
             if (any) { ph[5] += 1; ph[6] += __popcll(any); }
             for (uint32_t ty = 0; ty < 16u; ++ty) {
-                const unsigned long long m = __ballot(v && RT_REF_TYPE(s.cur) == ty);
+                const unsigned long long m = rt_ballot(v && RT_REF_TYPE(s.cur) == ty);
                 if (m) { ph[8 + ty] += 1; ph[24 + ty] += __popcll(m); }
             }
         }
