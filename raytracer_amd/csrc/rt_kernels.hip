@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
                     HeldRay held;
                     held.r = &s.r;
                     rt_extend_flat(sc, held, t_min, s.best, xi_of(id, path), skip_media);
-                    s.slab = rt_slab_of(s.r, sc.node_extent);
+                    s.slab = rt_slab_of<EXACT_NODES>(s.r, sc.node_extent);
                     s.cur = sc.world_tree;
                     st.clear();
                     active = true;
