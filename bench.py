@@ -281,14 +281,16 @@ def main():
             "roofline": {
                 # achieved / peak / frac: the kernel's ALGORITHMIC path-state bytes over its HIP-event time against the HBM
                 # peak (measured here). The kernel is not bound by HBM: the scene sits in L2 / LDS, and what limits it is
-                # f64 VALU issue under divergence - valu_busy x valu_lane_use, from the SQ counters (counters_from).
+                # the vector unit under divergence - valu_busy x valu_lane_use, from the SQ counters (counters_from) - and the
+                # chain of dependent steps a wave runs per node and leaf, with four waves per SIMD to overlap them.
                 "kernel": "k_extend_tree", "bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_segment": EXTEND_BYTES_PER_SEGMENT, "segments_per_launch": seg_per_launch,
                 "avg_launch_ms": avg_ms, "launches": int(stats.extend_launches), **valu,
                 "counters_from": counters_from,
-                "note": "cache-resident scene: bound by f64 VALU issue and latency under divergence (valu_busy x "
-                        "valu_lane_use = the share of VALU issue slots doing useful lanes), not by HBM; achieved/frac "
+                "note": "cache-resident scene: bound by VALU issue and the latency of each wave's dependent steps under "
+                        "divergence (valu_busy counts every instruction as 4 cycles; valu_busy x valu_lane_use = the share "
+                        "of VALU issue slots doing useful lanes), not by HBM; achieved/frac "
                         "are the compulsory path-state bytes against the HBM peak; traffic = HBM bytes per launch from "
                         "FETCH_SIZE x 2 + WRITE_SIZE at the pass size named in counters_from",
             },
