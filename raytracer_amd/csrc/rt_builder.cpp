@@ -468,8 +468,11 @@ uint32_t rt_builder::emit(Flat& f, int h, int parent, uint32_t depth, uint32_t& 
                         return RT_MAKE_ILEAF(chain, RT_REF_TYPE(c) == RT_REF_ILEAF ? RT_ILEAF_PRIM(c) : c);
                     }
                 }
-                // (over an RT_REF_ILEAF that found no room for the longer chain: an instance like any other, entered and left)
-                if (RT_REF_TYPE(c) != RT_REF_ILEAF) f.insts[me].op |= RT_INST_LEAF;
+                // The traversal follows RT_INST_LEAF records down to a primitive or medium reference. An instance over an
+                // RT_REF_ILEAF that found no room for the longer chain - or over such an instance - is one like any other,
+                // entered and left through a marker.
+                const uint32_t ct = RT_REF_TYPE(c);
+                if (ct != RT_REF_ILEAF && (ct != RT_REF_INST || (f.insts[RT_REF_INDEX(c)].op & RT_INST_LEAF) != 0u)) f.insts[me].op |= RT_INST_LEAF;
             }
         }
         need = std::max(2u, 1u + cneed);
@@ -1035,7 +1038,10 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
             uint32_t n = 0;
             const uint32_t r = emit(f, it.handle, RT_NO_PARENT, 0, n);
             if (r == RT_REF_NONE) { run_rc = error.empty() ? fail(RT_ERR_UNSUPPORTED, "empty scene") : RT_ERR_UNSUPPORTED; return out; }
-            if (lock_step && it.flatable) flat_refs.push_back(r);
+            // (the lock-step walk follows linked instance records down to a primitive or medium; a named leaf under linked
+            // records - its longer chain found the table full - is an instance that is entered and left: not for that list)
+            const bool enterable = RT_REF_TYPE(r) == RT_REF_INST && (f.insts[RT_REF_INDEX(r)].op & RT_INST_LEAF) == 0u;
+            if (lock_step && it.flatable && !enterable) flat_refs.push_back(r);
             else { loose_refs.push_back(r); need = std::max(need, n); }
         }
         if (!sah.empty()) {

@@ -606,6 +606,8 @@ RT_HD void rt_extend_flat(const DScene& sc, const RayFn& world_ray, double t_min
         uint32_t e = sc.list_entries[li];
         if (e == RT_REF_NONE) break;
         bool moved = false;
+        // (an entry is a primitive or medium, alone or below instances: named by its reference, RT_REF_ILEAF, or below linked
+        // records, RT_REF_INST - the compiler never puts a named leaf under linked records on this list)
         if (RT_REF_TYPE(e) == RT_REF_ILEAF) {
             r = rt_apply_chain(sc, RT_ILEAF_CHAIN(e), r);
             e = RT_ILEAF_PRIM(e);

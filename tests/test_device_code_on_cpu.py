@@ -168,7 +168,7 @@ def test_random_scene_graphs(seed):
         assert (want["prim_id"] != MISS).mean() > 0.01
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_instanced_leaves_in_every_encoding(variant):
     """A primitive under Translate / RotateY objects is named by chain and primitive number in the reference itself where
     both fit, by linked instance records where they do not: first hits, hit records and renders agree with the oracle
@@ -186,17 +186,26 @@ def test_instanced_leaves_in_every_encoding(variant):
             assert 7 in kinds and h["sections"]["chains"][1] == 64   # the table is full: the rest is linked records
         osc = ck.OracleScene(desc, share_bvh_axes=True)
         rng = np.random.default_rng(500 + variant)
-        rays = util.random_rays(rng, 4000, any_time=False)
+        rays = util.random_rays(rng, 12000 if variant == 2 else 4000, any_time=False)
         xi = rng.random((len(rays), osc.n_media)) if osc.n_media else None
         want = osc.trace_first_hit(rays, xi)
         got, _ = ck.hostsim_trace_first_hit(blob, rays, xi)
         rep = util.first_hit_report(got, want)
         assert rep["prim_match"] == 1.0 and rep["t_bit_equal"] == 1.0, (variant, flags, rep)
         hit = rep["both_hit"]
+        if variant == 2 and flags == 0:   # the object whose chain the table cut in two is among those the rays hit
+            INST = np.dtype([("a", "<f8"), ("b", "<f8"), ("c", "<f8"), ("op", "<u4"), ("child", "<u4"), ("parent", "<i4"), ("src", "<u4")])
+            insts = np.frombuffer(blob, dtype=INST, count=h["sections"]["insts"][1], offset=h["sections"]["insts"][0])
+            cut = [r for r in insts if int(r["child"]) >> 28 == 7 and int(insts[int(r["child"]) & 0x03FFFFFF]["child"]) >> 28 == 10]
+            assert len(cut) == 1 and cut[0]["op"] & 0x100 == 0 and insts[int(cut[0]["child"]) & 0x03FFFFFF]["op"] & 0x100 == 0
+            named = int(insts[int(cut[0]["child"]) & 0x03FFFFFF]["child"])
+            table = ("sphere_meta", "msphere_meta", "rect_meta", "box_meta")[(named >> 26) & 3]
+            meta = np.frombuffer(blob, dtype="<u4", count=h["sections"][table][1] * 4, offset=h["sections"][table][0]).reshape(-1, 4)
+            assert int(meta[named & 0xFFFFF][2]) in set(want["prim_id"][hit].tolist())
         for f in ("px", "py", "pz", "nx", "ny", "nz"):   # the hit record is rebuilt through the member's instance records
             assert util.abs_err(got[f][hit], want[f][hit]).max() < 1e-12, (variant, flags, f)
         assert np.array_equal(got["flags"][hit], want["flags"][hit]) and np.array_equal(got["material_id"][hit], want["material_id"][hit])
-        assert (want["prim_id"] != MISS).mean() > 0.1
+        assert (want["prim_id"] != MISS).mean() > (0.03 if variant == 2 else 0.1)
     cam = api.make_camera((0, 3, -24), (0, 0, 0), (0, 1, 0), 40.0, 4 / 3, 0.1, 20.0, 0.0, 1.0)
     p = api.make_params(20, 15, max_depth=10, background=(0.7, 0.8, 1.0), seed=91 + variant)
     a, _ = ck.hostsim_render(blob, cam, p, 2)

@@ -138,7 +138,7 @@ def test_random_scene_graphs_on_the_gpu(gpu_ctx, seed):
         scene.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_instanced_leaves_in_every_encoding_on_the_gpu(gpu_ctx, variant):
     """Primitives under Translate / RotateY named by chain and primitive number, and - past the 64 chains a reference can
     name - by linked instance records (see the CPU test of the same name): both kernels against the oracle, host-built,
@@ -152,7 +152,7 @@ def test_instanced_leaves_in_every_encoding_on_the_gpu(gpu_ctx, variant):
             try:
                 gpu_ctx.build_tree(scene)
             except api.RtError as e:   # (a world whose entries must keep their order leaves no tree to the device)
-                assert e.code == -1 and variant == 0
+                assert e.code == -1 and variant in (0, 2)
         rng = np.random.default_rng(500 + variant)
         rays = util.random_rays(rng, 20000, any_time=False)
         xi = rng.random((len(rays), osc.n_media)) if osc.n_media else None

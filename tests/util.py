@@ -270,7 +270,8 @@ def many_instances_scene(variant, flags=0):
        reference can name: the first get chain records, the rest fall back to linked instance records - some with the
        inner part of their chain named and the outer part not), in a world list and under a BvhNode;
     1: Translate over RotateY over a BvhNode of 300 spheres and boxes (members pushed down to the leaves, one shared chain)
-       beside RotateY over a list of rects, plus a medium whose boundary is an instanced box.
+       beside RotateY over a list of rects, plus a medium whose boundary is an instanced box;
+    2: 30 objects under three instances each, so that the chain table runs out in the middle of one object's chain.
     -> (builder, world)"""
     rng = np.random.default_rng(4242 + variant)
     b = api.Builder(seed=SCENE_SEED + 77 + variant, flags=flags)
@@ -286,6 +287,18 @@ def many_instances_scene(variant, flags=0):
             return b.xy_rect(float(c[0]), float(c[0] + 1.2), float(c[1]), float(c[1] + 0.9), float(c[2]), m)
         return b.sphere(tuple(c), float(rng.uniform(0.3, 0.9)), m)
 
+    if variant == 2:
+        # 30 objects under three instances each, no two steps alike: an object wants three chains (inner, inner two, all
+        # three), so the table's 64 places run out in the middle of the 22nd object the compiler meets, whichever that is -
+        # its innermost instance is named, the outer two are linked records over a named leaf
+        members = []
+        for k in range(30):
+            h = prim(7.0)
+            h = b.rotate_y(h, float(rng.uniform(-60, 60)))
+            h = b.translate(h, tuple(rng.uniform(-2, 2, 3)))
+            h = b.rotate_y(h, float(rng.uniform(-60, 60)))
+            members.append(h)
+        return b, b.list(members[:10] + [b.bvh(b.list(members[10:]), 0.0, 1.0)])
     if variant == 0:
         members = []
         for k in range(90):
