@@ -526,7 +526,10 @@ RT_HD void rt_trav_descend(const Nodes& nodes, RtTrav& s, Stack& st, double t_mi
     while (RT_REF_TYPE(s.cur) == RT_REF_NODE) rt_trav_node_step(nodes, s, st, t_min);
 }
 
-template <class Stack, class XiFn, class RayFn>
+// AHEAD = true: a sphere leaf's record, and the first two steps of the chain it is seen through, are all asked for before
+// any of them is used (one wait instead of up to four in a row; ~20 more registers at that point). For scenes that have
+// such leaves: -1.5 % traversal time on the Book-2 scene; a scene without chains loses 1 - 2.5 % to the same code.
+template <bool AHEAD = false, class Stack, class XiFn, class RayFn>
 RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, const XiFn& xi, bool skip_media,
                          const RayFn& world_ray) {
     const uint32_t idx = RT_REF_INDEX(s.cur);
@@ -548,8 +551,23 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
         uint32_t leaf = s.cur;
         Ray moved = s.r;
         if (type == RT_REF_ILEAF) leaf = RT_ILEAF_PRIM(s.cur);
+        constexpr bool ahead = AHEAD;
+        const bool sphere_ahead = ahead && RT_REF_TYPE(leaf) == RT_REF_SPHERE;
+        RtSphere sph;
+        sph.cx = 0.0; sph.cy = 0.0; sph.cz = 0.0; sph.r = 0.0;
+        if (sphere_ahead) sph = sc.spheres[RT_REF_INDEX(leaf)]; // (beside the chain's record)
         if (type == RT_REF_ILEAF) {
-            moved = rt_apply_chain(sc, RT_ILEAF_CHAIN(s.cur), moved);
+            if (ahead) {
+                const RtChain* ch = sc.chains + RT_ILEAF_CHAIN(s.cur);
+                const uint32_t n = ch->n;
+                const RtChainOp op0 = ch->op[0], op1 = ch->op[1]; // (unused steps of a record are zero-filled)
+                if (n > 0u) moved = rt_apply_chain_op(op0, moved);
+                if (n > 1u) moved = rt_apply_chain_op(op1, moved);
+#pragma unroll 1
+                for (uint32_t k = 2u; k < n && k < (uint32_t)RT_MAX_CHAIN; ++k) moved = rt_apply_chain_op(ch->op[k], moved);
+            } else {
+                moved = rt_apply_chain(sc, RT_ILEAF_CHAIN(s.cur), moved);
+            }
         } else if (type == RT_REF_INST) {
             RtInst in = sc.insts[idx];
             if ((in.op & RT_INST_LEAF) == 0u) { // a subtree in its own frame: enter it, leave through a POP marker
@@ -569,7 +587,13 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
                 in = sc.insts[RT_REF_INDEX(leaf)];
             }
         }
-        rt_test_leaf(sc, leaf, moved, t_min, s.best, xi, skip_media);
+        if (sphere_ahead) {
+            double t;
+            RT_VISIT(1u + RT_REF_SPHERE);
+            if (rt_sphere_t(v3(sph.cx, sph.cy, sph.cz), sph.r, moved, t_min, s.best.t, t)) { s.best.t = t; s.best.ref = leaf; s.best.aux = 0u; }
+        } else {
+            rt_test_leaf(sc, leaf, moved, t_min, s.best, xi, skip_media);
+        }
     }
     s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop();
 }

@@ -378,7 +378,9 @@ __device__ unsigned long long g_phase[4][48];
 // SPHERE_MEDIA = true: every ConstantMedium of the scene is bounded by a plain sphere.
 // QUERY = true: the rays are a caller's batch (`qb`) instead of the live paths of bounce `it`: same scheduling, same
 // node cache, same leaf rounds; per-ray t_min / t_max and injected medium uniforms.
-template <bool EXACT_NODES, bool SPHERE_MEDIA, bool QUERY, bool ALL_CACHED>
+// CHAINS = true: the scene has leaves named together with their Translate / RotateY chain (RT_REF_ILEAF), and the
+// instantiation the registers to ask for such a leaf's records all at once (rt_trav_visit<true>).
+template <bool EXACT_NODES, bool SPHERE_MEDIA, bool QUERY, bool ALL_CACHED, bool CHAINS = false>
 __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
                                                                uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_pct,
                                                                uint32_t n_cached, uint32_t n_exact_lds, QueryBatch qb) {
@@ -518,11 +520,11 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             if constexpr (QUERY) {
                 QueryRay ray_of;
                 ray_of.q = qb.rays + path;
-                rt_trav_visit(sc, s, st, t_min, xi_of(id, path), skip_media, ray_of);
+                rt_trav_visit<CHAINS>(sc, s, st, t_min, xi_of(id, path), skip_media, ray_of);
             } else {
                 SlotRay ray_of;
                 ray_of.rec = rays + path;
-                rt_trav_visit(sc, s, st, t_min, xi_of(id, path), skip_media, ray_of);
+                rt_trav_visit<CHAINS>(sc, s, st, t_min, xi_of(id, path), skip_media, ray_of);
             }
         }
         if (active && s.cur == RT_REF_NONE) { // finished: publish the closest hit
@@ -1024,6 +1026,12 @@ int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t f
 #undef RT_EXT_ROW
     const bool all_cached = n_cached == sc->hdr.nodes.count; // every node of the scene has a place in LDS
     out->kernel = table[exact_nodes][sphere_media][query][all_cached];
+    // leaves named with their chain, in an instantiation that has the registers for it: their records fetched together
+    if (sc->hdr.chains.count != 0u && !exact_nodes && sphere_media) {
+        static const ExtendKernel with_chains[2][2] = {{k_extend_tree<false, true, false, false, true>, k_extend_tree<false, true, false, true, true>},
+                                                       {k_extend_tree<false, true, true, false, true>, k_extend_tree<false, true, true, true, true>}};
+        out->kernel = with_chains[query][all_cached];
+    }
     if (lds > 65536)
         RT_HIP(hipFuncSetAttribute((const void*)out->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size of k_extend_tree");
     if (getenv("RT_DEBUG"))
