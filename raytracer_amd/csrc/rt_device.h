@@ -553,9 +553,17 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
         if (type == RT_REF_ILEAF) leaf = RT_ILEAF_PRIM(s.cur);
         constexpr bool ahead = AHEAD;
         const bool sphere_ahead = ahead && RT_REF_TYPE(leaf) == RT_REF_SPHERE;
-        RtSphere sph;
-        sph.cx = 0.0; sph.cy = 0.0; sph.cz = 0.0; sph.r = 0.0;
-        if (sphere_ahead) sph = sc.spheres[RT_REF_INDEX(leaf)]; // (beside the chain's record)
+        const bool box_ahead = ahead && RT_REF_TYPE(leaf) == RT_REF_BOX;
+        // (a sphere's four doubles or a box's six, asked for beside the chain's record and before the wave works through
+        // its kinds of leaves one after the other)
+        RtBox rec;
+        rec.p0[0] = 0.0; rec.p0[1] = 0.0; rec.p0[2] = 0.0; rec.p1[0] = 0.0; rec.p1[1] = 0.0; rec.p1[2] = 0.0;
+        if (sphere_ahead) {
+            const RtSphere sp = sc.spheres[RT_REF_INDEX(leaf)];
+            rec.p0[0] = sp.cx; rec.p0[1] = sp.cy; rec.p0[2] = sp.cz; rec.p1[0] = sp.r;
+        } else if (box_ahead) {
+            rec = sc.boxes[RT_REF_INDEX(leaf)];
+        }
         if (type == RT_REF_ILEAF) {
             if (ahead) {
                 const RtChain* ch = sc.chains + RT_ILEAF_CHAIN(s.cur);
@@ -590,7 +598,12 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
         if (sphere_ahead) {
             double t;
             RT_VISIT(1u + RT_REF_SPHERE);
-            if (rt_sphere_t(v3(sph.cx, sph.cy, sph.cz), sph.r, moved, t_min, s.best.t, t)) { s.best.t = t; s.best.ref = leaf; s.best.aux = 0u; }
+            if (rt_sphere_t(v3(rec.p0[0], rec.p0[1], rec.p0[2]), rec.p1[0], moved, t_min, s.best.t, t)) { s.best.t = t; s.best.ref = leaf; s.best.aux = 0u; }
+        } else if (box_ahead) {
+            double t;
+            uint32_t face = 0u;
+            RT_VISIT(1u + RT_REF_BOX);
+            if (rt_box_t(rec, moved, t_min, s.best.t, t, face)) { s.best.t = t; s.best.ref = leaf; s.best.aux = face; }
         } else {
             rt_test_leaf(sc, leaf, moved, t_min, s.best, xi, skip_media);
         }
