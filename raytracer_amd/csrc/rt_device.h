@@ -554,6 +554,7 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
         constexpr bool ahead = AHEAD;
         const bool sphere_ahead = ahead && RT_REF_TYPE(leaf) == RT_REF_SPHERE;
         const bool box_ahead = ahead && RT_REF_TYPE(leaf) == RT_REF_BOX;
+        const bool medium_ahead = ahead && RT_REF_TYPE(leaf) == RT_REF_MEDIUM && !skip_media;
         // (a sphere's four doubles or a box's six, asked for beside the chain's record and before the wave works through
         // its kinds of leaves one after the other)
         RtBox rec;
@@ -563,6 +564,9 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
             rec.p0[0] = sp.cx; rec.p0[1] = sp.cy; rec.p0[2] = sp.cz; rec.p1[0] = sp.r;
         } else if (box_ahead) {
             rec = sc.boxes[RT_REF_INDEX(leaf)];
+        } else if (medium_ahead) { // (32 bytes, kept as raw doubles until the medium's turn)
+            const double* raw = (const double*)(sc.media + RT_REF_INDEX(leaf));
+            rec.p0[0] = raw[0]; rec.p0[1] = raw[1]; rec.p0[2] = raw[2]; rec.p1[0] = raw[3];
         }
         if (type == RT_REF_ILEAF) {
             if (ahead) {
@@ -604,6 +608,14 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
             uint32_t face = 0u;
             RT_VISIT(1u + RT_REF_BOX);
             if (rt_box_t(rec, moved, t_min, s.best.t, t, face)) { s.best.t = t; s.best.ref = leaf; s.best.aux = face; }
+        } else if (medium_ahead) {
+            double t;
+            RtMedium m;
+            static_assert(sizeof(RtMedium) == 32, "RtMedium is fetched ahead as four doubles");
+            const double raw[4] = {rec.p0[0], rec.p0[1], rec.p0[2], rec.p1[0]};
+            __builtin_memcpy(&m, raw, sizeof m);
+            RT_VISIT(1u + RT_REF_MEDIUM);
+            if (rt_medium_t(sc, m, moved, t_min, s.best.t, xi, t)) { s.best.t = t; s.best.ref = leaf; s.best.aux = 0u; }
         } else {
             rt_test_leaf(sc, leaf, moved, t_min, s.best, xi, skip_media);
         }
