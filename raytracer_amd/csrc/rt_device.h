@@ -80,6 +80,11 @@ RT_HD Ray rt_apply_chain_op(const RtChainOp& in, const Ray& r) {
     }
     return o;
 }
+RT_HD V3 rt_apply_chain_op_dir(const RtChainOp& in, V3 d) { // the direction part
+    if ((in.op & RT_OP_MASK) == RT_OP_TRANSLATE) return d;
+    const double s = in.a, c = in.b;
+    return v3(c * d.x - s * d.z, d.y, s * d.x + c * d.z);
+}
 RT_HD Ray rt_apply_chain(const DScene& sc, uint32_t chain, Ray r) {
     const RtChain* ch = sc.chains + chain;
     const uint32_t n = ch->n;
@@ -730,19 +735,41 @@ RT_HD HitRec rt_reconstruct(const DScene& sc, const Ray& wray, const RtHitLite& 
     else if (type == RT_REF_BOX) { const RtMeta m = sc.box_meta[idx]; rec.material = m.material; rec.src_id = m.src_id; parent = m.parent_inst; }
     else { const RtMedium m = sc.media[idx]; rec.material = m.material; rec.src_id = m.src_id; parent = m.parent_inst; }
 
+    // The instances above the primitive, level 0 directly above it. Each level's record is read ONCE, on the way up the
+    // parent links, and the first RT_KEPT_LEVELS of them stay in registers: the way in, the way out and the directions
+    // in between use every level several times, and a read each time is a round trip to the cache each time, one after
+    // the other - that, not arithmetic, is what a wave with an instanced hit used to spend its time on.
+    constexpr int RT_KEPT_LEVELS = 2;
     int32_t chain[RT_MAX_CHAIN];
+    RtChainOp kept[RT_KEPT_LEVELS];
     {
         int32_t p = parent;
 #pragma unroll
         for (int k = 0; k < RT_MAX_CHAIN; ++k) {
             chain[k] = p;
-            if (p >= 0) p = sc.insts[p].parent_inst;
+            if (k < RT_KEPT_LEVELS) {
+                kept[k].a = 0.0; kept[k].b = 0.0; kept[k].c = 0.0; kept[k].op = RT_OP_TRANSLATE; kept[k].pad = 0u;
+                if (p >= 0) {
+                    const RtInst in = sc.insts[p];
+                    kept[k].a = in.a; kept[k].b = in.b; kept[k].c = in.c; kept[k].op = in.op;
+                    p = in.parent_inst;
+                }
+            } else if (p >= 0) {
+                p = sc.insts[p].parent_inst;
+            }
         }
     }
+    const auto level = [&](int k) {
+        if (k < RT_KEPT_LEVELS) return kept[k];
+        const RtInst in = sc.insts[chain[k]];
+        RtChainOp o;
+        o.a = in.a; o.b = in.b; o.c = in.c; o.op = in.op; o.pad = 0u;
+        return o;
+    };
     Ray r = wray;
 #pragma unroll
     for (int k = RT_MAX_CHAIN - 1; k >= 0; --k)
-        if (chain[k] >= 0) r = rt_apply_inst(sc.insts[chain[k]], r);
+        if (chain[k] >= 0) r = rt_apply_chain_op(level(k), r);
 
     rec.p = ray_at(r, h.t);
     if (type == RT_REF_SPHERE || type == RT_REF_MSPHERE) { // sphere.rs:57-61, moving_sphere.rs:63-66: (p - centre) / radius
@@ -773,13 +800,13 @@ RT_HD HitRec rt_reconstruct(const DScene& sc, const Ray& wray, const RtHitLite& 
 #pragma unroll
     for (int k = 0; k < RT_MAX_CHAIN; ++k) {
         if (chain[k] >= 0) {
-            const RtInst in = sc.insts[chain[k]];
+            const RtChainOp in = level(k);
             // the direction of the ray below instance chain[k] (what hittable.rs:80, 176 pass to set_face_normal), worked
             // out again from the world ray rather than kept from the way in: four kept directions are 24 registers
             V3 dir = wray.d;
 #pragma unroll
             for (int j = RT_MAX_CHAIN - 1; j >= k; --j)
-                if (chain[j] >= 0) dir = rt_apply_inst_dir(sc.insts[chain[j]], dir);
+                if (chain[j] >= 0) dir = rt_apply_chain_op_dir(level(j), dir);
             if ((in.op & RT_OP_MASK) == RT_OP_TRANSLATE) {
                 rec.p = rec.p + v3(in.a, in.b, in.c);
                 rt_set_face_normal(rec, dir, rec.normal);
