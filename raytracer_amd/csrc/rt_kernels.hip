@@ -228,6 +228,32 @@ __device__ inline uint32_t block_reserve(bool take, uint32_t which, uint32_t* co
     return sc[W] + sc[wave] + rank;
 }
 
+// The same for two items per thread (item 0 of every thread comes before item 1 of any in the wave's share).
+__device__ inline void block_reserve2(bool take0, uint32_t which0, bool take1, uint32_t which1, uint32_t* counter0, uint32_t* counter1,
+                                      uint32_t* scratch, uint32_t& pos0, uint32_t& pos1) {
+    constexpr uint32_t W = RT_BLOCK / 64u;
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long a0 = __ballot(take0 && which0 == 0u), a1 = __ballot(take0 && which0 != 0u);
+    const unsigned long long b0 = __ballot(take1 && which1 == 0u), b1 = __ballot(take1 && which1 != 0u);
+    const uint32_t rank0 = (uint32_t)__popcll((which0 == 0u ? a0 : a1) & below);
+    const uint32_t rank1 = (uint32_t)(__popcll(which1 == 0u ? a0 : a1) + __popcll((which1 == 0u ? b0 : b1) & below));
+    __syncthreads();
+    if (lane == 0u) { scratch[wave] = (uint32_t)(__popcll(a0) + __popcll(b0)); scratch[W + 1u + wave] = (uint32_t)(__popcll(a1) + __popcll(b1)); }
+    __syncthreads();
+    if (threadIdx.x < 2u) {
+        uint32_t* sc = scratch + threadIdx.x * (W + 1u);
+        uint32_t total = 0u;
+        for (uint32_t w = 0; w < W; ++w) { const uint32_t c = sc[w]; sc[w] = total; total += c; }
+        sc[W] = total ? atomicAdd(threadIdx.x == 0u ? counter0 : counter1, total) : 0u;
+    }
+    __syncthreads();
+    const uint32_t* s0 = scratch + (which0 == 0u ? 0u : W + 1u);
+    const uint32_t* s1 = scratch + (which1 == 0u ? 0u : W + 1u);
+    pos0 = s0[W] + s0[wave] + rank0;
+    pos1 = s1[W] + s1[wave] + rank1;
+}
+
 // R items per thread, each for one of Q queues (which[r] >= Q: none): one atomic per queue per call, two barriers.
 // Queue q starts at qbase + q * qcap and counts in counters[q]. `lds` = Q * RT_BLOCK/64 words. Every thread of the
 // block must call it; a barrier must separate two calls.
@@ -611,9 +637,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
 // now - these are nearly all hits, their code is short, and Lambertian and Isotropic share the same rejection loop, so
 // mixing them in a wave costs little; a hit on a computed texture (Perlin noise, image, checker) is queued for the
 // k_shade kernel of its bucket, which would otherwise drag its registers and code through every wave.
+// A workgroup takes 2 x RT_BLOCK paths at a time, every thread one path of each half, and reserves room in the next
+// bounce's arrays for both halves at once: at the first bounces the kernel ran at 82 reservations per microsecond on each
+// of the two counters, which is as many as one word takes. The first half's survivor waits in LDS meanwhile.
 __global__ void __launch_bounds__(RT_BLOCK, 5) k_shade_main(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it) {
     __shared__ uint32_t scratch[2 * (RT_BLOCK / 64 + 1)];
     __shared__ uint32_t lds[RT_QUEUES * (RT_BLOCK / 64)];
+    __shared__ double2 held[5 * RT_BLOCK]; // piece k of thread x's first survivor at [k * RT_BLOCK + x]: its ray record, then (t.r, t.g)
+    __shared__ double held_b[RT_BLOCK];    // ... and t.b
     uint32_t* ctr = qs.counters + it * RT_COUNTER_STRIDE;
     const LiveSet alive_paths = live_set(ctr, qs.bucket_cap);
     const uint32_t n = alive_paths.n();
@@ -623,69 +654,107 @@ __global__ void __launch_bounds__(RT_BLOCK, 5) k_shade_main(DScene sc, PassInfo 
     PathRay* next_rays = pb.ray[(it + 1u) & 1u];
     PathThr* next_thr = pb.thr[(it + 1u) & 1u];
     uint32_t* next_counter = qs.counters + (it + 1u) * RT_COUNTER_STRIDE;
-    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
-        const uint32_t i = alive_paths.record(base + threadIdx.x);
+    for (uint32_t base = blockIdx.x * (2u * RT_BLOCK); base < n; base += gridDim.x * (2u * RT_BLOCK)) {
         PathId id;
         id.slot = 0u; id.pixel = 0u;
         uint32_t end = 0u;
         bool alive = false;
-        uint32_t later[1] = {0xFFFFFFFFu};
-        const uint32_t path[1] = {i};
+        uint32_t first = 0xFFu; // what became of the first half's path: its queue (0xFF: none) | alive << 8 | end << 9 - one register across the second half
+        uint32_t later[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+        uint32_t path[2] = {0u, 0u};
         Ray scattered;
         PathThr t;
         scattered.o = v3(0.0, 0.0, 0.0); scattered.d = v3(0.0, 0.0, 0.0); scattered.tm = 0.0;
         t.r = 1.0; t.g = 1.0; t.b = 1.0;
-        if (base + threadIdx.x < n) {
-            const RtHitLite h = pb.hit[i];
-            const Ray r = load_ray(rays + i, id);
-            if (it != 0u) t = thr[i];
-            end = RT_REF_TYPE(h.ref) == RT_REF_MEDIUM ? 1u : 0u; // scattered inside a medium: back of the arrays
-            double* rad = pb.rad + 3u * (size_t)id.slot;
-            if (h.ref == RT_REF_NONE) { // main.rs:56-58: return background; the path ends here
-                const V3 bg = rt_background(pi.bg, pi.bg_mode, r);
-                rad[0] = t.r * bg.x;
-                rad[1] = t.g * bg.y;
-                rad[2] = t.b * bg.z;
-            } else {
-                const uint32_t ty = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
-                uint32_t mi;
-                if (ty == RT_REF_SPHERE) mi = sc.sphere_meta[idx].material;
-                else if (ty == RT_REF_MSPHERE) mi = sc.msphere_meta[idx].material;
-                else if (ty == RT_REF_RECT) mi = sc.rect_meta[idx].material;
-                else if (ty == RT_REF_BOX) mi = sc.box_meta[idx].material;
-                else mi = sc.media[idx].material;
-                const RtMaterial m = sc.materials[mi];
-                const bool textured = m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_DIFFUSE_LIGHT || m.type == RT_MAT_ISOTROPIC;
-                const uint32_t bucket = rt_bucket_of(m.type, textured ? m.tex_type : (uint32_t)RT_TEX_SOLID);
-                if (!rt_bucket_solid(bucket) && bucket != RT_BUCKET_METAL && bucket != RT_BUCKET_DIELECTRIC) {
-                    later[0] = rt_bucket_queue(bucket);
+#pragma unroll 1
+        for (uint32_t half = 0u; half < 2u; ++half) {
+            if (half == 1u) { // the first half's result steps aside
+                first = (later[1] & 0xFFu) | (alive ? 0x100u : 0u) | (end << 9);
+                if (alive) {
+                    double2* to = held + threadIdx.x;
+                    to[0] = make_double2(scattered.o.x, scattered.o.y);
+                    to[RT_BLOCK] = make_double2(scattered.o.z, scattered.d.x);
+                    to[2 * RT_BLOCK] = make_double2(scattered.d.y, scattered.d.z);
+                    to[3 * RT_BLOCK] = make_double2(scattered.tm, __longlong_as_double((long long)(((unsigned long long)id.pixel << 32) | id.slot)));
+                    to[4 * RT_BLOCK] = make_double2(t.r, t.g);
+                    held_b[threadIdx.x] = t.b;
+                }
+            }
+            const uint32_t number = base + half * RT_BLOCK + threadIdx.x;
+            const uint32_t i = alive_paths.record(number);
+            alive = false; end = 0u;
+            later[1] = 0xFFFFFFFFu; path[1] = i;
+            t.r = 1.0; t.g = 1.0; t.b = 1.0;
+            // (nothing of the first half's survivor is needed in registers any more)
+            scattered.o = v3(0.0, 0.0, 0.0); scattered.d = v3(0.0, 0.0, 0.0); scattered.tm = 0.0;
+            id.slot = 0u; id.pixel = 0u;
+            if (number < n) {
+                const RtHitLite h = pb.hit[i];
+                const Ray r = load_ray(rays + i, id);
+                if (it != 0u) t = thr[i];
+                end = RT_REF_TYPE(h.ref) == RT_REF_MEDIUM ? 1u : 0u; // scattered inside a medium: back of the arrays
+                double* rad = pb.rad + 3u * (size_t)id.slot;
+                if (h.ref == RT_REF_NONE) { // main.rs:56-58: return background; the path ends here
+                    const V3 bg = rt_background(pi.bg, pi.bg_mode, r);
+                    rad[0] = t.r * bg.x;
+                    rad[1] = t.g * bg.y;
+                    rad[2] = t.b * bg.z;
                 } else {
-                    const HitRec rec = rt_reconstruct(sc, r, h, false);
-                    const Sampler smp = slot_sampler(pi, id, it);
-                    const ShadeOut o = rt_shade_as<RT_MAT_COUNT, true>(sc, m, r, rec, smp);
-                    if (m.type == RT_MAT_DIELECTRIC) end = 1u; // glass keeps company with the media (one of them fills a glass sphere)
-                    // a path that used its last bounce adds nothing more: ray_color(depth <= 0) is black (main.rs:52-54)
-                    if (o.did_scatter && it + 1u < pi.max_depth) {
-                        alive = true;
-                        scattered = o.scattered;
-                        t.r *= o.attenuation.x; t.g *= o.attenuation.y; t.b *= o.attenuation.z;
-                    } else { // the path ends here (only DiffuseLight's emitted() is not black)
-                        rad[0] = t.r * o.emitted.x;
-                        rad[1] = t.g * o.emitted.y;
-                        rad[2] = t.b * o.emitted.z;
+                    const uint32_t ty = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
+                    uint32_t mi;
+                    if (ty == RT_REF_SPHERE) mi = sc.sphere_meta[idx].material;
+                    else if (ty == RT_REF_MSPHERE) mi = sc.msphere_meta[idx].material;
+                    else if (ty == RT_REF_RECT) mi = sc.rect_meta[idx].material;
+                    else if (ty == RT_REF_BOX) mi = sc.box_meta[idx].material;
+                    else mi = sc.media[idx].material;
+                    const RtMaterial m = sc.materials[mi];
+                    const bool textured = m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_DIFFUSE_LIGHT || m.type == RT_MAT_ISOTROPIC;
+                    const uint32_t bucket = rt_bucket_of(m.type, textured ? m.tex_type : (uint32_t)RT_TEX_SOLID);
+                    if (!rt_bucket_solid(bucket) && bucket != RT_BUCKET_METAL && bucket != RT_BUCKET_DIELECTRIC) {
+                        later[1] = rt_bucket_queue(bucket);
+                    } else {
+                        const HitRec rec = rt_reconstruct(sc, r, h, false);
+                        const Sampler smp = slot_sampler(pi, id, it);
+                        const ShadeOut o = rt_shade_as<RT_MAT_COUNT, true>(sc, m, r, rec, smp);
+                        if (m.type == RT_MAT_DIELECTRIC) end = 1u; // glass keeps company with the media (one of them fills a glass sphere)
+                        // a path that used its last bounce adds nothing more: ray_color(depth <= 0) is black (main.rs:52-54)
+                        if (o.did_scatter && it + 1u < pi.max_depth) {
+                            alive = true;
+                            scattered = o.scattered;
+                            t.r *= o.attenuation.x; t.g *= o.attenuation.y; t.b *= o.attenuation.z;
+                        } else { // the path ends here (only DiffuseLight's emitted() is not black)
+                            rad[0] = t.r * o.emitted.x;
+                            rad[1] = t.g * o.emitted.y;
+                            rad[2] = t.b * o.emitted.z;
+                        }
                     }
                 }
             }
         }
-        if (__syncthreads_or(later[0] != 0xFFFFFFFFu)) {
-            block_append_multi<1, RT_QUEUES>(later, path, qs.bucket, qs.bucket_cap, ctr + 1u, lds);
+        const bool alive0 = (first & 0x100u) != 0u;
+        const uint32_t end0 = (first >> 9) & 1u;
+        later[0] = (first & 0xFFu) == 0xFFu ? 0xFFFFFFFFu : (first & 0xFFu);
+        path[0] = alive_paths.record(base + threadIdx.x);
+        if (__syncthreads_or(later[0] != 0xFFFFFFFFu || later[1] != 0xFFFFFFFFu)) {
+            block_append_multi<2, RT_QUEUES>(later, path, qs.bucket, qs.bucket_cap, ctr + 1u, lds);
             __syncthreads();
         }
-        uint32_t j = block_reserve(alive, end, next_counter, next_counter + RT_COUNTER_BACK, scratch);
+        uint32_t j0, j1;
+        block_reserve2(alive0, end0, alive, end, next_counter, next_counter + RT_COUNTER_BACK, scratch, j0, j1);
         if (alive) {
-            if (end) j = cap - 1u - j;
-            store_ray(next_rays + j, scattered, id);
-            next_thr[j] = t;
+            if (end) j1 = cap - 1u - j1;
+            store_ray(next_rays + j1, scattered, id);
+            next_thr[j1] = t;
+        }
+        if (alive0) { // (each thread reads back what it wrote itself)
+            if (end0) j0 = cap - 1u - j0;
+            const double2* from = held + threadIdx.x;
+            double2* q = (double2*)(next_rays + j0);
+            q[0] = from[0]; q[1] = from[RT_BLOCK]; q[2] = from[2 * RT_BLOCK]; q[3] = from[3 * RT_BLOCK];
+            const double2 rg = from[4 * RT_BLOCK];
+            PathThr t0;
+            t0.r = rg.x; t0.g = rg.y; t0.b = held_b[threadIdx.x];
+            next_thr[j0] = t0;
         }
     }
 }
