@@ -228,7 +228,8 @@ __device__ inline uint32_t block_reserve(bool take, uint32_t which, uint32_t* co
     return sc[W] + sc[wave] + rank;
 }
 
-// The same for two items per thread (item 0 of every thread comes before item 1 of any in the wave's share).
+// The same for two items per thread (item 0 of every thread comes before item 1 of any in the wave's share). The caller
+// must have passed a barrier since the previous call.
 __device__ inline void block_reserve2(bool take0, uint32_t which0, bool take1, uint32_t which1, uint32_t* counter0, uint32_t* counter1,
                                       uint32_t* scratch, uint32_t& pos0, uint32_t& pos1) {
     constexpr uint32_t W = RT_BLOCK / 64u;
@@ -238,7 +239,7 @@ __device__ inline void block_reserve2(bool take0, uint32_t which0, bool take1, u
     const unsigned long long b0 = __ballot(take1 && which1 == 0u), b1 = __ballot(take1 && which1 != 0u);
     const uint32_t rank0 = (uint32_t)__popcll((which0 == 0u ? a0 : a1) & below);
     const uint32_t rank1 = (uint32_t)(__popcll(which1 == 0u ? a0 : a1) + __popcll((which1 == 0u ? b0 : b1) & below));
-    __syncthreads();
+    // (no barrier in front of the writes to `scratch`: the caller has had one since the last call read it)
     if (lane == 0u) { scratch[wave] = (uint32_t)(__popcll(a0) + __popcll(b0)); scratch[W + 1u + wave] = (uint32_t)(__popcll(a1) + __popcll(b1)); }
     __syncthreads();
     if (threadIdx.x < 2u) {
