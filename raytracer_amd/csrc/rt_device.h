@@ -728,6 +728,10 @@ RT_HD HitRec rt_reconstruct(const DScene& sc, const Ray& wray, const RtHitLite& 
     rec.v = 0.0;
     rec.front_face = false;
     const uint32_t type = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
+    // (a sphere's record is asked for together with its RtMeta, not after the walk up the instances that depends on that)
+    RtSphere sphere;
+    sphere.cx = 0.0; sphere.cy = 0.0; sphere.cz = 0.0; sphere.r = 1.0;
+    if (type == RT_REF_SPHERE) sphere = sc.spheres[idx];
     int32_t parent;
     if (type == RT_REF_SPHERE) { const RtMeta m = sc.sphere_meta[idx]; rec.material = m.material; rec.src_id = m.src_id; parent = m.parent_inst; }
     else if (type == RT_REF_MSPHERE) { const RtMeta m = sc.msphere_meta[idx]; rec.material = m.material; rec.src_id = m.src_id; parent = m.parent_inst; }
@@ -775,7 +779,7 @@ RT_HD HitRec rt_reconstruct(const DScene& sc, const Ray& wray, const RtHitLite& 
     if (type == RT_REF_SPHERE || type == RT_REF_MSPHERE) { // sphere.rs:57-61, moving_sphere.rs:63-66: (p - centre) / radius
         V3 centre;
         double radius;
-        if (type == RT_REF_SPHERE) { const RtSphere s = sc.spheres[idx]; centre = v3(s.cx, s.cy, s.cz); radius = s.r; }
+        if (type == RT_REF_SPHERE) { centre = v3(sphere.cx, sphere.cy, sphere.cz); radius = sphere.r; }
         else { const RtMSphere s = sc.mspheres[idx]; centre = rt_msphere_center(s, r.tm); radius = s.r; }
         V3 outward = (rec.p - centre) / radius;
         rt_set_face_normal(rec, r.d, outward);
