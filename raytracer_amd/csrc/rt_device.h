@@ -716,55 +716,73 @@ RT_HD void rt_sphere_uv(V3 p, double& u, double& v) {
     v = theta / RT_PI;
 }
 
+// What the tables say about a hit primitive - material, handle, the instance directly above it - and, for a sphere, its
+// record, asked for in the same breath.
+struct RtHitMeta {
+    uint32_t material, src_id;
+    int32_t parent;
+    RtSphere sphere;
+};
+RT_HD RtHitMeta rt_hit_meta(const DScene& sc, const RtHitLite& h) {
+    const uint32_t type = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
+    RtHitMeta g;
+    g.sphere.cx = 0.0; g.sphere.cy = 0.0; g.sphere.cz = 0.0; g.sphere.r = 1.0;
+    if (type == RT_REF_SPHERE) g.sphere = sc.spheres[idx];
+    if (type == RT_REF_SPHERE) { const RtMeta m = sc.sphere_meta[idx]; g.material = m.material; g.src_id = m.src_id; g.parent = m.parent_inst; }
+    else if (type == RT_REF_MSPHERE) { const RtMeta m = sc.msphere_meta[idx]; g.material = m.material; g.src_id = m.src_id; g.parent = m.parent_inst; }
+    else if (type == RT_REF_RECT) { const RtMeta m = sc.rect_meta[idx]; g.material = m.material; g.src_id = m.src_id; g.parent = m.parent_inst; }
+    else if (type == RT_REF_BOX) { const RtMeta m = sc.box_meta[idx]; g.material = m.material; g.src_id = m.src_id; g.parent = m.parent_inst; }
+    else { const RtMedium m = sc.media[idx]; g.material = m.material; g.src_id = m.src_id; g.parent = m.parent_inst; }
+    return g;
+}
+// The instances above a hit primitive, level 0 directly above it. Each level's record is read ONCE, on the way up the
+// parent links, and the first RT_KEPT_LEVELS of them stay in registers: the way in, the way out and the directions
+// in between use every level several times, and a read each time is a round trip to the cache each time, one after
+// the other - that, not arithmetic, is what a wave with an instanced hit used to spend its time on.
+#define RT_KEPT_LEVELS 2
+struct RtHitLevels {
+    int32_t chain[RT_MAX_CHAIN];
+    RtChainOp kept[RT_KEPT_LEVELS];
+};
+RT_HD RtHitLevels rt_hit_levels(const DScene& sc, int32_t parent) {
+    RtHitLevels lv;
+    int32_t p = parent;
+#pragma unroll
+    for (int k = 0; k < RT_MAX_CHAIN; ++k) {
+        lv.chain[k] = p;
+        if (k < RT_KEPT_LEVELS) {
+            lv.kept[k].a = 0.0; lv.kept[k].b = 0.0; lv.kept[k].c = 0.0; lv.kept[k].op = RT_OP_TRANSLATE; lv.kept[k].pad = 0u;
+            if (p >= 0) {
+                const RtInst in = sc.insts[p];
+                lv.kept[k].a = in.a; lv.kept[k].b = in.b; lv.kept[k].c = in.c; lv.kept[k].op = in.op;
+                p = in.parent_inst;
+            }
+        } else if (p >= 0) {
+            p = sc.insts[p].parent_inst;
+        }
+    }
+    return lv;
+}
+
 // Rebuilds the HitRecord the reference's nested hit() calls would have produced for the winning
 // primitive: local hit in the primitive's frame, then each enclosing Translate (hittable.rs:75-78)
 // and RotateY (hittable.rs:164-174, including its use of the already-overwritten x) outward.
 // MovingSphere and ConstantMedium never write u,v (moving_sphere.rs:63-68, constant_medium.rs:59-65);
 // they are 0 here. `want_uv` = false skips the acos/atan2 when no texture will read them.
-RT_HD HitRec rt_reconstruct(const DScene& sc, const Ray& wray, const RtHitLite& h, bool want_uv) {
+// `g`, `lv`: rt_hit_meta and rt_hit_levels of the hit - a caller with reads of its own to make (the material) puts them
+// between the two, so that they travel together with the first instance record instead of in front of it.
+RT_HD HitRec rt_reconstruct(const DScene& sc, const Ray& wray, const RtHitLite& h, bool want_uv, const RtHitMeta& g, const RtHitLevels& lv) {
     HitRec rec;
     rec.t = h.t;
     rec.u = 0.0;
     rec.v = 0.0;
     rec.front_face = false;
     const uint32_t type = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
-    // (a sphere's record is asked for together with its RtMeta, not after the walk up the instances that depends on that)
-    RtSphere sphere;
-    sphere.cx = 0.0; sphere.cy = 0.0; sphere.cz = 0.0; sphere.r = 1.0;
-    if (type == RT_REF_SPHERE) sphere = sc.spheres[idx];
-    int32_t parent;
-    if (type == RT_REF_SPHERE) { const RtMeta m = sc.sphere_meta[idx]; rec.material = m.material; rec.src_id = m.src_id; parent = m.parent_inst; }
-    else if (type == RT_REF_MSPHERE) { const RtMeta m = sc.msphere_meta[idx]; rec.material = m.material; rec.src_id = m.src_id; parent = m.parent_inst; }
-    else if (type == RT_REF_RECT) { const RtMeta m = sc.rect_meta[idx]; rec.material = m.material; rec.src_id = m.src_id; parent = m.parent_inst; }
-    else if (type == RT_REF_BOX) { const RtMeta m = sc.box_meta[idx]; rec.material = m.material; rec.src_id = m.src_id; parent = m.parent_inst; }
-    else { const RtMedium m = sc.media[idx]; rec.material = m.material; rec.src_id = m.src_id; parent = m.parent_inst; }
-
-    // The instances above the primitive, level 0 directly above it. Each level's record is read ONCE, on the way up the
-    // parent links, and the first RT_KEPT_LEVELS of them stay in registers: the way in, the way out and the directions
-    // in between use every level several times, and a read each time is a round trip to the cache each time, one after
-    // the other - that, not arithmetic, is what a wave with an instanced hit used to spend its time on.
-    constexpr int RT_KEPT_LEVELS = 2;
-    int32_t chain[RT_MAX_CHAIN];
-    RtChainOp kept[RT_KEPT_LEVELS];
-    {
-        int32_t p = parent;
-#pragma unroll
-        for (int k = 0; k < RT_MAX_CHAIN; ++k) {
-            chain[k] = p;
-            if (k < RT_KEPT_LEVELS) {
-                kept[k].a = 0.0; kept[k].b = 0.0; kept[k].c = 0.0; kept[k].op = RT_OP_TRANSLATE; kept[k].pad = 0u;
-                if (p >= 0) {
-                    const RtInst in = sc.insts[p];
-                    kept[k].a = in.a; kept[k].b = in.b; kept[k].c = in.c; kept[k].op = in.op;
-                    p = in.parent_inst;
-                }
-            } else if (p >= 0) {
-                p = sc.insts[p].parent_inst;
-            }
-        }
-    }
+    rec.material = g.material; rec.src_id = g.src_id;
+    const RtSphere sphere = g.sphere;
+    const int32_t (&chain)[RT_MAX_CHAIN] = lv.chain;
     const auto level = [&](int k) {
-        if (k < RT_KEPT_LEVELS) return kept[k];
+        if (k < RT_KEPT_LEVELS) return lv.kept[k];
         const RtInst in = sc.insts[chain[k]];
         RtChainOp o;
         o.a = in.a; o.b = in.b; o.c = in.c; o.op = in.op; o.pad = 0u;
@@ -834,6 +852,10 @@ RT_HD HitRec rt_reconstruct(const DScene& sc, const Ray& wray, const RtHitLite& 
         }
     }
     return rec;
+}
+RT_HD HitRec rt_reconstruct(const DScene& sc, const Ray& wray, const RtHitLite& h, bool want_uv) {
+    const RtHitMeta g = rt_hit_meta(sc, h);
+    return rt_reconstruct(sc, wray, h, want_uv, g, rt_hit_levels(sc, g.parent));
 }
 
 // ---- textures ------------------------------------------------------------------------------------------

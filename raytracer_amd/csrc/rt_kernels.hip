@@ -701,20 +701,17 @@ __global__ void __launch_bounds__(RT_BLOCK, 5) k_shade_main(DScene sc, PassInfo 
                     rad[1] = t.g * bg.y;
                     rad[2] = t.b * bg.z;
                 } else {
-                    const uint32_t ty = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
-                    uint32_t mi;
-                    if (ty == RT_REF_SPHERE) mi = sc.sphere_meta[idx].material;
-                    else if (ty == RT_REF_MSPHERE) mi = sc.msphere_meta[idx].material;
-                    else if (ty == RT_REF_RECT) mi = sc.rect_meta[idx].material;
-                    else if (ty == RT_REF_BOX) mi = sc.box_meta[idx].material;
-                    else mi = sc.media[idx].material;
-                    const RtMaterial m = sc.materials[mi];
+                    // the material is asked for between the primitive's table entry and the instance records above it: it
+                    // and the first of those depend on the entry alone and travel together
+                    const RtHitMeta g = rt_hit_meta(sc, h);
+                    const RtMaterial m = sc.materials[g.material];
+                    const RtHitLevels lv = rt_hit_levels(sc, g.parent);
                     const bool textured = m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_DIFFUSE_LIGHT || m.type == RT_MAT_ISOTROPIC;
                     const uint32_t bucket = rt_bucket_of(m.type, textured ? m.tex_type : (uint32_t)RT_TEX_SOLID);
                     if (!rt_bucket_solid(bucket) && bucket != RT_BUCKET_METAL && bucket != RT_BUCKET_DIELECTRIC) {
                         later[1] = rt_bucket_queue(bucket);
                     } else {
-                        const HitRec rec = rt_reconstruct(sc, r, h, false);
+                        const HitRec rec = rt_reconstruct(sc, r, h, false, g, lv);
                         const Sampler smp = slot_sampler(pi, id, it);
                         const ShadeOut o = rt_shade_as<RT_MAT_COUNT, true>(sc, m, r, rec, smp);
                         if (m.type == RT_MAT_DIELECTRIC) end = 1u; // glass keeps company with the media (one of them fills a glass sphere)
