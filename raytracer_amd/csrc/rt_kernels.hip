@@ -681,7 +681,9 @@ __global__ void __launch_bounds__(RT_BLOCK, 5) k_shade_main(DScene sc, PassInfo 
                     held_b[threadIdx.x] = t.b;
                 }
             }
-            const uint32_t number = base + half * RT_BLOCK + threadIdx.x;
+            // (a wave's two halves are 128 paths in a row, so that its survivors leave in the order the paths came in:
+            // neighbours in the arrays are samples of one pixel, and the traversal likes them together)
+            const uint32_t number = base + ((threadIdx.x >> 6) * 2u + half) * 64u + (threadIdx.x & 63u);
             const uint32_t i = alive_paths.record(number);
             alive = false; end = 0u;
             later[1] = 0xFFFFFFFFu; path[1] = i;
@@ -732,7 +734,7 @@ __global__ void __launch_bounds__(RT_BLOCK, 5) k_shade_main(DScene sc, PassInfo 
         const bool alive0 = (first & 0x100u) != 0u;
         const uint32_t end0 = (first >> 9) & 1u;
         later[0] = (first & 0xFFu) == 0xFFu ? 0xFFFFFFFFu : (first & 0xFFu);
-        path[0] = alive_paths.record(base + threadIdx.x);
+        path[0] = alive_paths.record(base + (threadIdx.x >> 6) * 128u + (threadIdx.x & 63u));
         if (__syncthreads_or(later[0] != 0xFFFFFFFFu || later[1] != 0xFFFFFFFFu)) {
             block_append_multi<2, RT_QUEUES>(later, path, qs.bucket, qs.bucket_cap, ctr + 1u, lds);
             __syncthreads();
