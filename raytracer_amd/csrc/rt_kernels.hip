@@ -599,16 +599,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
             const Ray r = load_ray(rays + path, id);
             const RtHitLite h = pb.hit[path];
             if (it != 0u) t = thr[path];
-            const uint32_t ty = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
-            uint32_t mi;
-            if (ty == RT_REF_SPHERE) mi = sc.sphere_meta[idx].material;
-            else if (ty == RT_REF_MSPHERE) mi = sc.msphere_meta[idx].material;
-            else if (ty == RT_REF_RECT) mi = sc.rect_meta[idx].material;
-            else if (ty == RT_REF_BOX) mi = sc.box_meta[idx].material;
-            else mi = sc.media[idx].material;
-            const RtMaterial m = sc.materials[mi];
+            // (the material is asked for between the primitive's table entry and the instance records above it, as in k_shade_main)
+            const RtHitMeta g = rt_hit_meta(sc, h);
+            const RtMaterial m = sc.materials[g.material];
+            const RtHitLevels lv = rt_hit_levels(sc, g.parent);
             const bool uv = (SOLID || MAT == RT_MAT_METAL || MAT == RT_MAT_DIELECTRIC || BUCKET == RT_BUCKET_LAMBERTIAN_NOISE) ? false : rt_material_reads_uv(sc, m);
-            const HitRec rec = rt_reconstruct(sc, r, h, uv);
+            const HitRec rec = rt_reconstruct(sc, r, h, uv, g, lv);
             const Sampler smp = slot_sampler(pi, id, it);
             const ShadeOut o = rt_shade_as<MAT, SOLID, BUCKET == RT_BUCKET_LAMBERTIAN_NOISE>(sc, m, r, rec, smp);
             // a path that used its last bounce adds nothing more: ray_color(depth <= 0) is black (main.rs:52-54)
