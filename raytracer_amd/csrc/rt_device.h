@@ -38,6 +38,13 @@ struct DScene {
     uint32_t n_media;
     uint32_t compat; // bit 0: book-correct RotateY back-rotation; bit 1: book-correct XY lens disk
     double node_extent; // largest finite |coordinate| of any node box
+    // When the lock-step list is exactly one ConstantMedium bounded by a plain sphere (a fog around the whole scene), its
+    // records ride here, in the kernel's arguments: scalar reads that do not queue behind the rays a refill has just
+    // asked for, instead of three dependent vector reads (list entry, medium, sphere) with the whole wave waiting.
+    uint32_t flat_one_medium; // 0: walk the list; else the medium's reference
+    uint32_t flat_pad;
+    RtMedium flat_medium;
+    RtSphere flat_sphere;
 };
 #define RT_COMPAT_BOOK_ROTATE 1u
 #define RT_COMPAT_BOOK_LENS 2u
@@ -344,12 +351,12 @@ template <class T> struct RtOnlySphereMedia<T, decltype((void)T::only_sphere_med
 // only asked for once the ray is known to cross the boundary.
 template <class XiFn>
 RT_HD bool rt_medium_t(const DScene& sc, const RtMedium& m, const Ray& r, double t_min, double t_max, const XiFn& xi,
-                       double& t_out) {
+                       double& t_out, const RtSphere* boundary_sphere = nullptr) {
     double t1 = 0.0, t2 = 0.0;
-    if (RtOnlySphereMedia<XiFn>::value || RT_REF_TYPE(m.boundary) == RT_REF_SPHERE) {
+    if (boundary_sphere != nullptr || RtOnlySphereMedia<XiFn>::value || RT_REF_TYPE(m.boundary) == RT_REF_SPHERE) {
         // The two boundary tests on a plain sphere are Sphere::hit (sphere.rs:34-64) twice on the same ray: same
         // discriminant, same two quotients, only the range differs - computed once, compared twice.
-        const RtSphere s = sc.spheres[RT_REF_INDEX(m.boundary)];
+        const RtSphere s = boundary_sphere != nullptr ? *boundary_sphere : sc.spheres[RT_REF_INDEX(m.boundary)]; // (the caller may hold the record already)
         const V3 oc = r.o - v3(s.cx, s.cy, s.cz);
         const double a = v3_sqlen(r.d);
         const double half_b = v3_dot(r.d, oc);
@@ -654,6 +661,14 @@ RT_HD void rt_traverse(const DScene& sc, uint32_t root, const Ray& r, double t_m
 template <class XiFn, class RayFn>
 RT_HD void rt_extend_flat(const DScene& sc, const RayFn& world_ray, double t_min, RtBest& best, const XiFn& xi, bool skip_media) {
     if (sc.world_flat == RT_REF_NONE) return;
+    if (sc.flat_one_medium != 0u) {
+        if (!skip_media) {
+            double t;
+            RT_VISIT(1u + RT_REF_MEDIUM);
+            if (rt_medium_t(sc, sc.flat_medium, world_ray(), t_min, best.t, xi, t, &sc.flat_sphere)) { best.t = t; best.ref = sc.flat_one_medium; best.aux = 0u; }
+        }
+        return;
+    }
     Ray r = world_ray();
 #pragma unroll 1
     for (uint32_t li = RT_REF_INDEX(sc.world_flat);; ++li) {

@@ -877,6 +877,13 @@ struct rt_scene {
     uint32_t bucket_mask = 0;              // shading buckets some material of the scene falls into
     bool sphere_media = true;              // every medium is bounded by a plain sphere (no instance, no other primitive)
     bool tree_built = false;               // rt_scene_build_tree_device has replaced the stand-in tree
+    // [0]: hdr.world_flat, [1]: hdr.world_flat_any_time - the list's one medium and its sphere when that is all the list holds
+    struct OneMedium { uint32_t ref = 0u; RtMedium medium; RtSphere sphere; } one_medium[2];
+    void choose_flat(uint32_t which) { // the list the view's world_flat names, as DScene::flat_one_medium wants it
+        view.flat_one_medium = one_medium[which].ref;
+        view.flat_medium = one_medium[which].medium;
+        view.flat_sphere = one_medium[which].sphere;
+    }
 };
 
 struct rt_context {
@@ -966,6 +973,9 @@ void make_view(rt_scene* s) {
     v.n_media = h.n_media;
     v.compat = 0;
     v.node_extent = h.node_extent;
+    v.flat_one_medium = 0u; v.flat_pad = 0u;
+    memset(&v.flat_medium, 0, sizeof v.flat_medium);
+    memset(&v.flat_sphere, 0, sizeof v.flat_sphere);
 }
 
 int ensure_paths(rt_context* ctx, size_t paths, uint32_t max_depth) {
@@ -1224,6 +1234,30 @@ static int upload_common(rt_context* ctx, const void* src, size_t nbytes, bool s
                           src_on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost);
         if (e != hipSuccess) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_NO_DEVICE, "read media", e); }
         for (const RtMedium& m : media) s->sphere_media = s->sphere_media && RT_REF_TYPE(m.boundary) == RT_REF_SPHERE;
+        // a lock-step list that is one medium bounded by a plain sphere, alone: its two records go into the scene view
+        std::vector<uint32_t> entries(s->hdr.list_entries.count);
+        const hipMemcpyKind kind = src_on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost;
+        if (!entries.empty()) e = hipMemcpy(entries.data(), (const uint8_t*)src + s->hdr.list_entries.offset, entries.size() * sizeof(uint32_t), kind);
+        if (e != hipSuccess) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_NO_DEVICE, "read list entries", e); }
+        const uint32_t lists[2] = {s->hdr.world_flat, s->hdr.world_flat_any_time};
+        for (int w = 0; w < 2; ++w) {
+            memset(&s->one_medium[w].medium, 0, sizeof(RtMedium));
+            memset(&s->one_medium[w].sphere, 0, sizeof(RtSphere));
+            if (lists[w] == RT_REF_NONE || RT_REF_TYPE(lists[w]) != RT_REF_LIST) continue;
+            const size_t li = RT_REF_INDEX(lists[w]);
+            if (li + 1 >= entries.size() || entries[li + 1] != RT_REF_NONE) continue; // not exactly one entry
+            const uint32_t ref = entries[li];
+            if (RT_REF_TYPE(ref) != RT_REF_MEDIUM || RT_REF_INDEX(ref) >= media.size()) continue;
+            const RtMedium& m = media[RT_REF_INDEX(ref)];
+            if (RT_REF_TYPE(m.boundary) != RT_REF_SPHERE || RT_REF_INDEX(m.boundary) >= s->hdr.spheres.count) continue;
+            RtSphere sp;
+            e = hipMemcpy(&sp, (const uint8_t*)src + s->hdr.spheres.offset + (size_t)RT_REF_INDEX(m.boundary) * sizeof(RtSphere), sizeof sp, kind);
+            if (e != hipSuccess) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_NO_DEVICE, "read a medium's sphere", e); }
+            s->one_medium[w].ref = ref;
+            s->one_medium[w].medium = m;
+            s->one_medium[w].sphere = sp;
+        }
+        s->choose_flat(1u); // (make_view names the any-time list)
     }
     *out = s;
     return RT_OK;
@@ -1467,7 +1501,7 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
     local.view.compat = p->compat;
     // every ray of this render has its time in the camera's shutter interval (camera.rs:62): when the bounds the
     // compiler gave moving spheres in the tree hold for all of it, those spheres need no lock-step test
-    if (cam->time0 >= sc->hdr.shutter0 && cam->time1 <= sc->hdr.shutter1 && cam->time0 <= cam->time1) local.view.world_flat = sc->hdr.world_flat;
+    if (cam->time0 >= sc->hdr.shutter0 && cam->time1 <= sc->hdr.shutter1 && cam->time0 <= cam->time1) { local.view.world_flat = sc->hdr.world_flat; local.choose_flat(0u); }
 
     ExtendLaunch xl;
     rc = extend_launch_of(ctx, sc, false, 0u, &xl);

@@ -65,6 +65,8 @@ bool view_of(const void* blob, size_t nbytes, DScene& v, RtBlobHeader& h) {
     v.texels = (const uint8_t*)(b + h.texels.offset);
     v.exact_boxes = (const RtExactBox*)(b + h.exact_boxes.offset);
     v.chains = (const RtChain*)(b + h.chains.offset);
+    v.flat_one_medium = 0u; v.flat_pad = 0u;
+    memset(&v.flat_medium, 0, sizeof v.flat_medium); memset(&v.flat_sphere, 0, sizeof v.flat_sphere);
     v.world = RT_REF_NONE;
     v.world_flat = h.world_flat_any_time;
     v.world_tree = h.world_tree;
