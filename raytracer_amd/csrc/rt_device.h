@@ -658,10 +658,13 @@ RT_HD void rt_traverse(const DScene& sc, uint32_t root, const Ray& r, double t_m
 
 // The world entries that are a primitive or a medium, possibly wrapped in Translate / RotateY: every lane
 // tests the same entry at the same time, so entry and parameters are wave-uniform (scalar loads, no stack).
-template <class XiFn, class RayFn>
+// ONE_MEDIUM: compiled with the short cut for a list that is one sphere-bounded medium (DScene::flat_one_medium). The
+// traversal kernel's instantiations are short of registers, each in its own way; only the one that scenes like the
+// Book-2 scene get carries it (elsewhere the same few lines cost 1 - 1.5 % of the kernel's time and won nothing).
+template <bool ONE_MEDIUM = false, class XiFn, class RayFn>
 RT_HD void rt_extend_flat(const DScene& sc, const RayFn& world_ray, double t_min, RtBest& best, const XiFn& xi, bool skip_media) {
     if (sc.world_flat == RT_REF_NONE) return;
-    if (sc.flat_one_medium != 0u) {
+    if (ONE_MEDIUM && sc.flat_one_medium != 0u) {
         if (!skip_media) {
             double t;
             RT_VISIT(1u + RT_REF_MEDIUM);

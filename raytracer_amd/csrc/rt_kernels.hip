@@ -406,7 +406,8 @@ __device__ unsigned long long g_phase[4][48];
 // QUERY = true: the rays are a caller's batch (`qb`) instead of the live paths of bounce `it`: same scheduling, same
 // node cache, same leaf rounds; per-ray t_min / t_max and injected medium uniforms.
 // CHAINS = true: the scene has leaves named together with their Translate / RotateY chain (RT_REF_ILEAF), and the
-// instantiation the registers to ask for such a leaf's records all at once (rt_trav_visit<true>).
+// instantiation the registers to ask for such a leaf's records all at once (rt_trav_visit<true>); it also carries the
+// short cut for a lock-step list that is one sphere-bounded medium (rt_extend_flat<true>).
 template <bool EXACT_NODES, bool SPHERE_MEDIA, bool QUERY, bool ALL_CACHED, bool CHAINS = false>
 __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
                                                                uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_pct,
@@ -496,7 +497,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
                     // the world entries every ray is tested against, by the lanes that just took a ray, in lock step
                     HeldRay held;
                     held.r = &s.r;
-                    rt_extend_flat(sc, held, t_min, s.best, xi_of(id, path), skip_media);
+                    rt_extend_flat<CHAINS>(sc, held, t_min, s.best, xi_of(id, path), skip_media);
                     s.slab = rt_slab_of<EXACT_NODES>(s.r, sc.node_extent);
                     s.cur = sc.world_tree;
                     st.clear();
