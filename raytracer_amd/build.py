@@ -7,6 +7,12 @@ product   raytracer_amd/librt_hip.so     HIP kernels for gfx950 + host scene bui
 oracle    oracle/liboracle.so            CPU restatement of the reference (test infrastructure)
 hostsim   tests/hostsim/libhostsim.so    per-lane device code compiled for the CPU (test tool)
 
+    python -m raytracer_amd.build --sanitize   # build/san/: the three libraries with the host code under ASan + UBSan
+
+The sanitized set (librt_hip_san.so: host side of the product, i.e. scene builder, compiler, named scenes and the C ABI;
+libhostsim_san.so: the per-lane device code on the CPU, with every reference checked against its section's length,
+-DRT_BOUNDS_CHECK; liboracle_san.so) is what tools/sanitize.sh runs the CPU parity tests on. GPU code is not instrumented.
+
 All three are compiled with -ffp-contract=off: the reference (Rust) never fuses a*b+c, and bit-level
 agreement between the CPU checker and the GPU depends on neither side doing so.
 """
@@ -66,6 +72,36 @@ def build_hostsim(force=False):
     return HOSTSIM_SO
 
 
+SAN_DIR = os.path.join(ROOT, "build", "san")
+SAN_FLAGS = ["-fsanitize=address", "-fsanitize=undefined", "-fno-omit-frame-pointer"]
+
+
+def clang_asan_runtime():
+    """The shared ASan runtime of the clang that hipcc drives: a sanitized shared library loaded into an uninstrumented
+    python needs it preloaded."""
+    out = subprocess.check_output(["/opt/rocm/lib/llvm/bin/clang++", "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+    return out
+
+
+def build_sanitized():
+    """Host code of all three libraries under AddressSanitizer + UndefinedBehaviorSanitizer (one compiler for all of them,
+    the clang behind hipcc, so that one runtime serves the process)."""
+    os.makedirs(SAN_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    srcs = [os.path.join(CSRC, f) for f in ("rt_kernels.hip", "rt_tree_build.hip", "rt_builder.cpp", "rt_scenes.cpp")]
+    host_only = []
+    for f in SAN_FLAGS:  # (each flag directly behind its -Xarch_host: the device side is compiled without sanitizers)
+        host_only += ["-Xarch_host", f]
+    _run([hipcc, "-O1", "-g", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wno-unused-value",
+          "-Wno-unused-result", *host_only, "-shared-libsan", *srcs, "-o", os.path.join(SAN_DIR, "librt_hip_san.so")])
+    common = [clang, "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", *SAN_FLAGS, "-shared-libsan"]
+    _run([*common, "-DRT_BOUNDS_CHECK", os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp"), "-o", os.path.join(SAN_DIR, "libhostsim_san.so"),
+          "-L" + SAN_DIR, "-lrt_hip_san", "-Wl,-rpath," + SAN_DIR])
+    _run([*common, "-pthread", os.path.join(ROOT, "oracle", "oracle.cpp"), "-o", os.path.join(SAN_DIR, "liboracle_san.so")])
+    return SAN_DIR
+
+
 def build_all(force=False):
     build_product(force)
     build_oracle(force)
@@ -74,6 +110,9 @@ def build_all(force=False):
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["all"]
+    if "--sanitize" in what:
+        build_sanitized()
+        sys.exit(0)
     force = "--force" in what
     what = [w for w in what if not w.startswith("--")] or ["all"]
     for w in what:

@@ -13,6 +13,27 @@
 #define RT_INF (__builtin_inf())
 #endif
 
+// Debug builds (-DRT_BOUNDS_CHECK: `python -m raytracer_amd.build --sanitize`, tools/build_checked_lib.sh) carry the
+// length of every section beside its pointer and check each reference before it is followed: the type it names and its
+// index. A violation is printed (host and device) and the access is skipped; the host build aborts, so that a sanitizer run
+// stops at the first one. Release builds compile none of it.
+#ifdef RT_BOUNDS_CHECK
+#include <stdio.h>
+#include <stdlib.h>
+struct RtCounts { uint32_t nodes, spheres, mspheres, rects, boxes, media, insts, list_entries, materials, textures, exact_boxes, chains; };
+RT_HD bool rt_in_range(const char* what, uint32_t idx, uint32_t n, uint32_t ref) {
+    if (idx < n) return true;
+    printf("rt bounds: %s index %u is not below %u (reference %08x)\n", what, idx, n, ref);
+#if !defined(__HIP_DEVICE_COMPILE__)
+    abort();
+#endif
+    return false;
+}
+#define RT_IN_RANGE(sc, section, idx, ref) rt_in_range(#section, (uint32_t)(idx), (sc).counts.section, (uint32_t)(ref))
+#else
+#define RT_IN_RANGE(sc, section, idx, ref) true
+#endif
+
 // Device-side view of an uploaded blob: typed pointers to its sections.
 struct DScene {
     const RtNode* nodes;
@@ -45,6 +66,9 @@ struct DScene {
     uint32_t flat_pad;
     RtMedium flat_medium;
     RtSphere flat_sphere;
+#ifdef RT_BOUNDS_CHECK
+    RtCounts counts;
+#endif
 };
 #define RT_COMPAT_BOOK_ROTATE 1u
 #define RT_COMPAT_BOOK_LENS 2u
@@ -428,6 +452,15 @@ RT_HD void rt_test_leaf(const DScene& sc, uint32_t ref, const Ray& r, double t_m
     const uint32_t idx = RT_REF_INDEX(ref);
     double t;
     RT_VISIT(1u + RT_REF_TYPE(ref));
+#ifdef RT_BOUNDS_CHECK
+    {
+        const uint32_t ty = RT_REF_TYPE(ref);
+        const bool known = ty == RT_REF_SPHERE ? RT_IN_RANGE(sc, spheres, idx, ref) : ty == RT_REF_MSPHERE ? RT_IN_RANGE(sc, mspheres, idx, ref)
+                         : ty == RT_REF_RECT ? RT_IN_RANGE(sc, rects, idx, ref) : ty == RT_REF_BOX ? RT_IN_RANGE(sc, boxes, idx, ref)
+                         : ty == RT_REF_MEDIUM ? RT_IN_RANGE(sc, media, idx, ref) : rt_in_range("leaf reference type", ty, 0u, ref);
+        if (!known) return;
+    }
+#endif
     switch (RT_REF_TYPE(ref)) {
     case RT_REF_SPHERE: {
         const RtSphere s = sc.spheres[idx];
@@ -485,6 +518,9 @@ struct RtTrav {
 struct GlobalNodes {
     const RtNode* nodes;
     const RtExactBox* exact; // f64 bounds of the boxes whose verdict is behaviour (RtNode::pad[1])
+#ifdef RT_BOUNDS_CHECK
+    uint32_t n_nodes;
+#endif
     RT_HD RtNode load(uint32_t index) const { return rt_load_node(nodes + index); }
     RT_HD RtExactBox exact_box(uint32_t k) const { return exact[k]; }
 };
@@ -504,6 +540,9 @@ RT_HD uint32_t rt_stack_node_step(Stack& st, bool both, bool any, uint32_t go, u
 template <bool EXACT_NODES = true, class Stack, class Nodes>
 RT_HD void rt_trav_node_step(const Nodes& nodes, RtTrav& s, Stack& st, double t_min) {
     const uint32_t under = rt_stack_prefetch(st, 0);
+#ifdef RT_BOUNDS_CHECK
+    if (!rt_in_range("nodes", RT_REF_INDEX(s.cur), nodes.n_nodes, s.cur)) { s.cur = RT_REF_NONE; return; }
+#endif
     const RtNode n = nodes.load(RT_REF_INDEX(s.cur));
     RT_VISIT(0u);
     bool h0, h1, swap;
@@ -546,6 +585,16 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
                          const RayFn& world_ray) {
     const uint32_t idx = RT_REF_INDEX(s.cur);
     const uint32_t type = RT_REF_TYPE(s.cur);
+#ifdef RT_BOUNDS_CHECK
+    {
+        bool ok = true;
+        if (type == RT_REF_LIST) ok = RT_IN_RANGE(sc, list_entries, idx, s.cur);
+        else if (type == RT_REF_POP || type == RT_REF_INST) ok = RT_IN_RANGE(sc, insts, idx, s.cur);
+        else if (type == RT_REF_ILEAF) ok = RT_IN_RANGE(sc, chains, RT_ILEAF_CHAIN(s.cur), s.cur);
+        else if (type > RT_REF_ILEAF || type == RT_REF_NODE || type == RT_REF_NONE) ok = rt_in_range("reference type at a leaf", type, 0u, s.cur);
+        if (!ok) { s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop(); return; }
+    }
+#endif
     if (type == RT_REF_LIST) { // HittableList: entries in order (hittable_list.rs:45-51)
         const uint32_t e = sc.list_entries[idx];
         if (e != RT_REF_NONE) {
@@ -571,6 +620,10 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
         // its kinds of leaves one after the other)
         RtBox rec;
         rec.p0[0] = 0.0; rec.p0[1] = 0.0; rec.p0[2] = 0.0; rec.p1[0] = 0.0; rec.p1[1] = 0.0; rec.p1[2] = 0.0;
+#ifdef RT_BOUNDS_CHECK
+        if ((sphere_ahead && !RT_IN_RANGE(sc, spheres, RT_REF_INDEX(leaf), s.cur)) || (box_ahead && !RT_IN_RANGE(sc, boxes, RT_REF_INDEX(leaf), s.cur)) ||
+            (medium_ahead && !RT_IN_RANGE(sc, media, RT_REF_INDEX(leaf), s.cur))) { s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop(); return; }
+#endif
         if (sphere_ahead) {
             const RtSphere sp = sc.spheres[RT_REF_INDEX(leaf)];
             rec.p0[0] = sp.cx; rec.p0[1] = sp.cy; rec.p0[2] = sp.cz; rec.p1[0] = sp.r;
@@ -647,6 +700,9 @@ RT_HD void rt_traverse(const DScene& sc, uint32_t root, const Ray& r, double t_m
     GlobalNodes nodes;
     nodes.nodes = sc.nodes;
     nodes.exact = sc.exact_boxes;
+#ifdef RT_BOUNDS_CHECK
+    nodes.n_nodes = sc.counts.nodes;
+#endif
 #pragma unroll 1
     for (;;) {
         rt_trav_descend(nodes, s, st, t_min);
@@ -745,12 +801,24 @@ RT_HD RtHitMeta rt_hit_meta(const DScene& sc, const RtHitLite& h) {
     const uint32_t type = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
     RtHitMeta g;
     g.sphere.cx = 0.0; g.sphere.cy = 0.0; g.sphere.cz = 0.0; g.sphere.r = 1.0;
+#ifdef RT_BOUNDS_CHECK
+    {   // a closest hit names a primitive or a medium by its own table: nothing else may arrive here
+        const bool known = type == RT_REF_SPHERE ? RT_IN_RANGE(sc, spheres, idx, h.ref) : type == RT_REF_MSPHERE ? RT_IN_RANGE(sc, mspheres, idx, h.ref)
+                         : type == RT_REF_RECT ? RT_IN_RANGE(sc, rects, idx, h.ref) : type == RT_REF_BOX ? RT_IN_RANGE(sc, boxes, idx, h.ref)
+                         : type == RT_REF_MEDIUM ? RT_IN_RANGE(sc, media, idx, h.ref) : rt_in_range("hit reference type", type, 0u, h.ref);
+        if (!known || (type == RT_REF_BOX && !rt_in_range("box face", h.aux, 6u, h.ref))) { g.material = 0u; g.src_id = 0xFFFFFFFFu; g.parent = RT_NO_PARENT; return g; }
+    }
+#endif
     if (type == RT_REF_SPHERE) g.sphere = sc.spheres[idx];
     if (type == RT_REF_SPHERE) { const RtMeta m = sc.sphere_meta[idx]; g.material = m.material; g.src_id = m.src_id; g.parent = m.parent_inst; }
     else if (type == RT_REF_MSPHERE) { const RtMeta m = sc.msphere_meta[idx]; g.material = m.material; g.src_id = m.src_id; g.parent = m.parent_inst; }
     else if (type == RT_REF_RECT) { const RtMeta m = sc.rect_meta[idx]; g.material = m.material; g.src_id = m.src_id; g.parent = m.parent_inst; }
     else if (type == RT_REF_BOX) { const RtMeta m = sc.box_meta[idx]; g.material = m.material; g.src_id = m.src_id; g.parent = m.parent_inst; }
     else { const RtMedium m = sc.media[idx]; g.material = m.material; g.src_id = m.src_id; g.parent = m.parent_inst; }
+#ifdef RT_BOUNDS_CHECK
+    if (!RT_IN_RANGE(sc, materials, g.material, h.ref)) g.material = 0u;
+    if (g.parent >= 0 && !RT_IN_RANGE(sc, insts, g.parent, h.ref)) g.parent = RT_NO_PARENT;
+#endif
     return g;
 }
 // The instances above a hit primitive, level 0 directly above it. Each level's record is read ONCE, on the way up the
@@ -770,12 +838,12 @@ RT_HD RtHitLevels rt_hit_levels(const DScene& sc, int32_t parent) {
         lv.chain[k] = p;
         if (k < RT_KEPT_LEVELS) {
             lv.kept[k].a = 0.0; lv.kept[k].b = 0.0; lv.kept[k].c = 0.0; lv.kept[k].op = RT_OP_TRANSLATE; lv.kept[k].pad = 0u;
-            if (p >= 0) {
+            if (p >= 0 && RT_IN_RANGE(sc, insts, p, 0u)) {
                 const RtInst in = sc.insts[p];
                 lv.kept[k].a = in.a; lv.kept[k].b = in.b; lv.kept[k].c = in.c; lv.kept[k].op = in.op;
                 p = in.parent_inst;
             }
-        } else if (p >= 0) {
+        } else if (p >= 0 && RT_IN_RANGE(sc, insts, p, 0u)) {
             p = sc.insts[p].parent_inst;
         }
     }
@@ -797,6 +865,9 @@ RT_HD HitRec rt_reconstruct(const DScene& sc, const Ray& wray, const RtHitLite& 
     rec.front_face = false;
     const uint32_t type = RT_REF_TYPE(h.ref), idx = RT_REF_INDEX(h.ref);
     rec.material = g.material; rec.src_id = g.src_id;
+#ifdef RT_BOUNDS_CHECK
+    if (g.src_id == 0xFFFFFFFFu) { rec.p = v3(0.0, 0.0, 0.0); rec.normal = v3(0.0, 0.0, 0.0); return rec; } // rt_hit_meta has reported it
+#endif
     const RtSphere sphere = g.sphere;
     const int32_t (&chain)[RT_MAX_CHAIN] = lv.chain;
     const auto level = [&](int k) {

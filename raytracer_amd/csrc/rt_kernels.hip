@@ -146,6 +146,9 @@ struct CachedNodes {
     uint32_t n_cached;
     const RtNode* global;
     const RtExactBox* exact; // f64 bounds of the boxes whose verdict is behaviour (RtNode::pad[1])
+#ifdef RT_BOUNDS_CHECK
+    uint32_t n_nodes;
+#endif
     const __attribute__((address_space(3))) double* exact_lds; // ... and the workgroup's copy of the first n_exact_lds of them
     uint32_t n_exact_lds;
     __device__ RtExactBox exact_box(uint32_t k) const {
@@ -442,6 +445,9 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
         nodes.n_cached = n_cached;
         nodes.global = sc.nodes;
         nodes.exact = sc.exact_boxes;
+#ifdef RT_BOUNDS_CHECK
+        nodes.n_nodes = sc.counts.nodes;
+#endif
         // behind the node records and the queue counter: the f64 bounds of the exact nodes, when there is room for all of them
         double* exact_copy = (double*)(cache + (size_t)n_cached * 4u + 1u);
         for (uint32_t i = threadIdx.x; i < n_exact_lds * 6u; i += blockDim.x) exact_copy[i] = ((const double*)sc.exact_boxes)[i];
@@ -975,6 +981,11 @@ void make_view(rt_scene* s) {
     v.compat = 0;
     v.node_extent = h.node_extent;
     v.flat_one_medium = 0u; v.flat_pad = 0u;
+#ifdef RT_BOUNDS_CHECK
+    v.counts = RtCounts{(uint32_t)h.nodes.count, (uint32_t)h.spheres.count, (uint32_t)h.mspheres.count, (uint32_t)h.rects.count, (uint32_t)h.boxes.count,
+                        (uint32_t)h.media.count, (uint32_t)h.insts.count, (uint32_t)h.list_entries.count, (uint32_t)h.materials.count,
+                        (uint32_t)h.textures.count, (uint32_t)h.exact_boxes.count, (uint32_t)h.chains.count};
+#endif
     memset(&v.flat_medium, 0, sizeof v.flat_medium);
     memset(&v.flat_sphere, 0, sizeof v.flat_sphere);
 }

@@ -12,7 +12,7 @@ from raytracer_amd.api import HIT_DTYPE, RAY_DTYPE
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # (bench.py times a build of the same source made for the host it runs on, and names it here)
 ORACLE_SO = os.environ.get("RT_ORACLE_SO") or os.path.join(ROOT, "oracle", "liboracle.so")
-HOSTSIM_SO = os.path.join(ROOT, "tests", "hostsim", "libhostsim.so")
+HOSTSIM_SO = os.environ.get("RT_HOSTSIM_SO") or os.path.join(ROOT, "tests", "hostsim", "libhostsim.so")
 _P = C.c_void_p
 
 

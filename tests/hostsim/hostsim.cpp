@@ -66,6 +66,11 @@ bool view_of(const void* blob, size_t nbytes, DScene& v, RtBlobHeader& h) {
     v.exact_boxes = (const RtExactBox*)(b + h.exact_boxes.offset);
     v.chains = (const RtChain*)(b + h.chains.offset);
     v.flat_one_medium = 0u; v.flat_pad = 0u;
+#ifdef RT_BOUNDS_CHECK
+    v.counts = RtCounts{(uint32_t)h.nodes.count, (uint32_t)h.spheres.count, (uint32_t)h.mspheres.count, (uint32_t)h.rects.count, (uint32_t)h.boxes.count,
+                        (uint32_t)h.media.count, (uint32_t)h.insts.count, (uint32_t)h.list_entries.count, (uint32_t)h.materials.count,
+                        (uint32_t)h.textures.count, (uint32_t)h.exact_boxes.count, (uint32_t)h.chains.count};
+#endif
     memset(&v.flat_medium, 0, sizeof v.flat_medium); memset(&v.flat_sphere, 0, sizeof v.flat_sphere);
     v.world = RT_REF_NONE;
     v.world_flat = h.world_flat_any_time;
