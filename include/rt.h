@@ -216,8 +216,9 @@ int rt_trace_first_hit(rt_context*, const rt_scene*, const rt_ray_d* rays, size_
 int rt_trace_first_hit_wavefront(rt_context*, const rt_scene*, const rt_ray_d* rays, size_t n, const double* medium_xi,
                                  rt_hit* out, uint32_t variant);
 
-/* rt_trace_first_hit without any allocation. No counterpart in the reference: it is for callers that cannot allocate
- * device memory while they run - code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+/* rt_trace_first_hit without any device allocation. No counterpart in the reference: it is for callers that cannot
+ * allocate device memory while they run - tight serving loops, harnesses that forbid hipMalloc. (It allocates nothing;
+ * it still copies from the caller's pageable host memory and waits for the result, so a HIP graph capture cannot record it.)
  * Same arguments and same results, bit for bit; the staging copies of rays, uniforms and hit records and the kernel's
  * overflow flag live in a fixed 16 MiB work area that the library holds on every GPU it runs on, so the batch is
  * limited: n * (72 + 96 + 8 * n_media [0 when medium_xi is NULL]) <= 16 MiB - 768 bytes (about 99 000 rays without
@@ -241,6 +242,21 @@ int rt_render_accumulate(rt_context*, const rt_scene*, const rt_camera*, const r
  * rgb8_out (nullable) = the reference's pixel conversion (main.rs:172-189). */
 int rt_render(rt_context*, const rt_scene*, const rt_camera*, const rt_params*, uint32_t spp,
               double* rgb_sum_out, uint8_t* rgb8_out, rt_stats* stats);
+
+/* The partition and the gather that main() wraps round the sample loop (main.rs:135-152: row bands dealt to the workers
+ * of a thread pool, each sharing the scene through Arc::clone; :192 every job sends its band; :242-253 the bands are
+ * copied into the image), over the GPUs of one node. ctxs[0 .. n_ctx) are contexts of this process - normally one per
+ * device (rt_init(&c, i) for i < rt_device_count()), several on one device work too. The compiled scene `blob` is
+ * uploaded to the first context's device and copied from there to every other device directly (GPU to GPU: xGMI on a
+ * fully connected node); context i, on a host thread of its own, renders every sample of the 32x32 tiles k with
+ * k % n_ctx == i (tile_rank / tile_world of `params` are overwritten); the per-context buffers travel to the first
+ * device, where each context's tiles are taken from its buffer, and the image comes back as rt_render returns it.
+ * Random numbers are keyed on (pixel, sample, bounce), so the image is the one-context image bit for bit for any n_ctx.
+ * stats (nullable): n_ctx records, one per context. Errors are reported on ctxs[0]. No context may be in use elsewhere
+ * during the call. */
+int rt_device_count(void); /* HIP devices visible to the process (0 when there is none) */
+int rt_render_multi(rt_context* const* ctxs, uint32_t n_ctx, const void* blob, size_t nbytes, const rt_camera*, const rt_params*,
+                    uint32_t spp, double* rgb_sum_out, uint8_t* rgb8_out, rt_stats* stats);
 
 /* main.rs:172-189 on the host for an already gathered sum buffer */
 void rt_tonemap(const double* rgb_sum, size_t n_pixels, double spp, uint8_t* rgb8_out);

@@ -177,6 +177,8 @@ extern "C" {
     pub fn rt_generate_rays(ctx: *mut rt_context, camera: *const rt_camera, params: *const rt_params, sample: u32, out: *mut rt_ray_d) -> c_int;
     pub fn rt_render_accumulate(ctx: *mut rt_context, scene: *const rt_scene, camera: *const rt_camera, params: *const rt_params, sample_offset: u32, spp: u32, d_rgb_sum: *mut f64, stats: *mut rt_stats) -> c_int;
     pub fn rt_render(ctx: *mut rt_context, scene: *const rt_scene, camera: *const rt_camera, params: *const rt_params, spp: u32, rgb_sum_out: *mut f64, rgb8_out: *mut u8, stats: *mut rt_stats) -> c_int;
+    pub fn rt_device_count() -> c_int;
+    pub fn rt_render_multi(ctxs: *const *mut rt_context, n_ctx: u32, blob: *const c_void, nbytes: usize, camera: *const rt_camera, params: *const rt_params, spp: u32, rgb_sum_out: *mut f64, rgb8_out: *mut u8, stats: *mut rt_stats) -> c_int;
     pub fn rt_tonemap(rgb_sum: *const f64, n_pixels: usize, spp: f64, rgb8_out: *mut u8);
     pub fn rt_device_alloc(ctx: *mut rt_context, nbytes: usize, d_ptr: *mut *mut c_void) -> c_int;
     pub fn rt_device_free(ctx: *mut rt_context, d_ptr: *mut c_void) -> c_int;

@@ -26,6 +26,47 @@ impl Vec3 {
     fn arr(&self) -> [f64; 3] {
         [self.x, self.y, self.z]
     }
+    /// vec3.rs:30-36, 50-55
+    pub fn length(&self) -> f64 {
+        (self.x * self.x + self.y * self.y + self.z * self.z).sqrt()
+    }
+    pub fn unit(&self) -> Self {
+        let l = self.length();
+        assert!(l != 0.0, "div 0!");
+        Self::new(self.x / l, self.y / l, self.z / l)
+    }
+    /// vec3.rs:102-110: a point of the unit disk in the XZ plane (as the reference has it)
+    pub fn random_in_unit_disk() -> Self {
+        loop {
+            let p = Self::new(random_double(-1.0, 1.0), 0.0, random_double(-1.0, 1.0));
+            if p.x * p.x + p.z * p.z < 1.0 {
+                return p;
+            }
+        }
+    }
+}
+impl std::ops::Add for Vec3 {
+    type Output = Vec3;
+    fn add(self, o: Vec3) -> Vec3 {
+        Vec3::new(self.x + o.x, self.y + o.y, self.z + o.z)
+    }
+}
+impl std::ops::Mul<f64> for Vec3 {
+    type Output = Vec3;
+    fn mul(self, s: f64) -> Vec3 {
+        Vec3::new(self.x * s, self.y * s, self.z * s)
+    }
+}
+
+/// rtweekend.rs:19-22. Scene functions draw their own random numbers on the host, as in the reference (`rand` is its
+/// dependency, not this crate's: a 64-bit LCG seeded once stands in, so that a build is repeatable).
+pub fn random_double(low: f64, high: f64) -> f64 {
+    use std::sync::atomic::AtomicU64;
+    static STATE: AtomicU64 = AtomicU64::new(0x5EED_0001_2545_F491);
+    let mut s = STATE.load(Ordering::Relaxed);
+    s = s.wrapping_mul(6364136223846793005).wrapping_add(1442695040888963407);
+    STATE.store(s, Ordering::Relaxed);
+    low + (high - low) * ((s >> 11) as f64 * (1.0 / 9007199254740992.0))
 }
 
 static BUILDER: AtomicPtr<ffi::rt_builder> = AtomicPtr::new(std::ptr::null_mut());

@@ -229,6 +229,21 @@ class Context:
         assert rgb_sum.size == n * 3
         return (rgb_sum, rgb8) if want_rgb8 else rgb_sum
 
+    @staticmethod
+    def render_multi(contexts, blob, camera, params, spp, want_rgb8=False, stats=None):
+        """rt_render_multi: the compiled scene `blob` rendered by several contexts at once, tiles dealt round-robin, scene
+        copied and image gathered GPU to GPU inside the library. `stats`: a list that receives one rt_stats per context."""
+        rgb_sum = np.zeros((params.height, params.width, 3), dtype=np.float64)
+        rgb8 = np.zeros((params.height, params.width, 3), dtype=np.uint8) if want_rgb8 else None
+        handles = (C.c_void_p * len(contexts))(*[c._c for c in contexts])
+        st = (rt_stats * len(contexts))()
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        contexts[0]._chk(lib.rt_render_multi(handles, len(contexts), buf, len(blob), C.byref(camera), C.byref(params), spp,
+                                             rgb_sum.ctypes.data, rgb8.ctypes.data if want_rgb8 else None, st))
+        if stats is not None:
+            stats.extend(st)
+        return (rgb_sum, rgb8) if want_rgb8 else rgb_sum
+
     def render_more(self, scene, camera, params, rgb_sum, samples_done, spp, stats=None):
         """Continues a render: adds samples [samples_done, samples_done + spp) of every pixel to the host array
         rgb_sum (height, width, 3) and returns it. Random numbers are keyed on (pixel, sample, bounce), so the result is

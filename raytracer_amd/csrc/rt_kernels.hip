@@ -29,6 +29,7 @@
 #include <new>
 #include <type_traits>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt.h"
@@ -802,6 +803,23 @@ __global__ void __launch_bounds__(RT_BLOCK) k_accumulate(PassInfo pi, PathBufs p
 
 __global__ void __launch_bounds__(RT_BLOCK) k_set_u32(uint32_t* p, uint32_t v) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *p = v;
+}
+
+// The gather of main.rs:244-253 (each job's rows copied into the image) for tile sharding: the pixels of the tiles that
+// belong to `rank` (tile k of the image belongs to rank k % world, as ensure_pixmap deals them) are taken from `src`, a
+// whole-image buffer that rank rendered into; every other pixel of `dst` is left alone.
+__global__ void __launch_bounds__(RT_BLOCK) k_merge_tiles(double* dst, const double* src, uint32_t width, uint32_t height, uint32_t tile,
+                                                          uint32_t rank, uint32_t world) {
+    const uint32_t n = width * height, tx = (width + tile - 1u) / tile;
+    for (uint32_t p = blockIdx.x * RT_BLOCK + threadIdx.x; p < n; p += gridDim.x * RT_BLOCK) {
+        const uint32_t y = p / width, x = p - y * width;
+        const uint32_t k = (y / tile) * tx + x / tile;
+        if (k % world == rank) {
+            dst[3u * (size_t)p] = src[3u * (size_t)p];
+            dst[3u * (size_t)p + 1u] = src[3u * (size_t)p + 1u];
+            dst[3u * (size_t)p + 2u] = src[3u * (size_t)p + 2u];
+        }
+    }
 }
 
 // What world.hit leaves in rec (hittable.rs:9-18) for closest hit `h` of ray `r`, as the record the C ABI reports.
@@ -1629,6 +1647,105 @@ int rt_render(rt_context* ctx, const rt_scene* sc, const rt_camera* cam, const r
         if (e != hipSuccess) rc = ctx_fail(ctx, RT_ERR_NO_DEVICE, "download framebuffer", e);
     }
     hipFree(d_sum);
+    if (rc == RT_OK && rgb8_out) rt_tonemap(rgb_sum_out, (size_t)p->width * p->height, (double)spp, rgb8_out);
+    return rc;
+} RT_ABI_CATCH
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n < 0 ? 0 : n;
+}
+
+int rt_render_multi(rt_context* const* ctxs, uint32_t n_ctx, const void* blob, size_t nbytes, const rt_camera* cam, const rt_params* p,
+                    uint32_t spp, double* rgb_sum_out, uint8_t* rgb8_out, rt_stats* stats) try {
+    if (!ctxs || n_ctx == 0u || !ctxs[0]) return RT_ERR_INVALID;
+    rt_context* ctx = ctxs[0]; // errors are reported on the first context
+    for (uint32_t i = 0; i < n_ctx; ++i) {
+        if (!ctxs[i]) return ctx_fail(ctx, RT_ERR_INVALID, "render_multi: null context");
+        for (uint32_t j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) return ctx_fail(ctx, RT_ERR_INVALID, "render_multi: the same context twice (a context serves one host thread at a time)");
+    }
+    if (!blob || !cam || !p || !rgb_sum_out) return ctx_fail(ctx, RT_ERR_INVALID, "render_multi: null argument");
+    if (p->width < 2 || p->height < 2) return ctx_fail(ctx, RT_ERR_INVALID, "render_multi: width/height must be >= 2");
+    const size_t n_doubles = (size_t)p->width * p->height * 3;
+    struct Rank {
+        rt_scene* scene = nullptr;
+        void* d_blob = nullptr; // the blob as it arrived on this rank's device (ranks > 0)
+        double* d_sum = nullptr;
+        int rc = RT_OK;
+        rt_stats st;
+    };
+    std::vector<Rank> ranks(n_ctx);
+    auto cleanup = [&]() {
+        for (uint32_t i = 0; i < n_ctx; ++i) {
+            hipSetDevice(ctxs[i]->device);
+            if (ranks[i].scene) rt_scene_free(ctxs[i], ranks[i].scene);
+            if (ranks[i].d_blob) hipFree(ranks[i].d_blob);
+            if (ranks[i].d_sum) hipFree(ranks[i].d_sum);
+        }
+    };
+    // The scene goes to the first context's device from the host once, and from there to every other device directly
+    // (the role of Arc::clone(&world) per job, main.rs:145): GPU to GPU over xGMI, a one-hop fan-out on a fully connected
+    // node - hipMemcpyPeer; for two contexts on one device a plain device copy.
+    int rc = rt_scene_upload(ctxs[0], blob, nbytes, &ranks[0].scene);
+    if (rc != RT_OK) { cleanup(); return rc; }
+    for (uint32_t i = 1; i < n_ctx && rc == RT_OK; ++i) {
+        hipError_t e = hipSetDevice(ctxs[i]->device);
+        if (e == hipSuccess) e = hipMalloc(&ranks[i].d_blob, nbytes);
+        if (e == hipSuccess) e = hipMemcpyPeer(ranks[i].d_blob, ctxs[i]->device, ranks[0].scene->d_blob, ctxs[0]->device, nbytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); rc = ctx_fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_NO_DEVICE, "render_multi: scene broadcast", e); break; }
+        rc = rt_scene_upload_from_device(ctxs[i], ranks[i].d_blob, nbytes, &ranks[i].scene);
+        if (rc != RT_OK) ctx_fail(ctx, rc, rt_last_error(ctxs[i]));
+    }
+    for (uint32_t i = 0; i < n_ctx && rc == RT_OK; ++i) {
+        hipError_t e = hipSetDevice(ctxs[i]->device);
+        if (e == hipSuccess) e = hipMalloc((void**)&ranks[i].d_sum, n_doubles * sizeof(double));
+        if (e == hipSuccess) e = hipMemsetAsync(ranks[i].d_sum, 0, n_doubles * sizeof(double), ctxs[i]->stream);
+        if (e != hipSuccess) { (void)hipGetLastError(); rc = ctx_fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_NO_DEVICE, "render_multi: framebuffer", e); }
+    }
+    if (rc != RT_OK) { cleanup(); return rc; }
+    // One host thread per context, as the reference has one worker per job (main.rs:143-148): rank i renders every sample of
+    // the tiles k with k % n_ctx == i. Random numbers are keyed on the pixel, so the split changes no bit of the image.
+    {
+        std::vector<std::thread> workers;
+        for (uint32_t i = 0; i < n_ctx; ++i) {
+            workers.emplace_back([&, i]() {
+                rt_params mine = *p;
+                mine.tile_rank = i; mine.tile_world = n_ctx;
+                memset(&ranks[i].st, 0, sizeof(rt_stats));
+                ranks[i].rc = rt_render_accumulate(ctxs[i], ranks[i].scene, cam, &mine, 0u, spp, ranks[i].d_sum, &ranks[i].st);
+            });
+        }
+        for (std::thread& w : workers) w.join();
+    }
+    for (uint32_t i = 0; i < n_ctx; ++i) {
+        if (ranks[i].rc != RT_OK && rc == RT_OK) { rc = ranks[i].rc; if (i) ctx_fail(ctx, rc, rt_last_error(ctxs[i])); }
+        if (stats) stats[i] = ranks[i].st;
+    }
+    // Gather (main.rs:242-253): every other rank's buffer travels to the first device and its tiles are taken from it.
+    if (rc == RT_OK && n_ctx > 1u) {
+        hipError_t e = hipSetDevice(ctxs[0]->device);
+        double* d_stage = nullptr;
+        if (e == hipSuccess) e = hipMalloc((void**)&d_stage, n_doubles * sizeof(double));
+        const uint32_t tile = p->tile ? p->tile : 32u;
+        for (uint32_t i = 1; i < n_ctx && e == hipSuccess; ++i) {
+            e = hipMemcpyPeerAsync(d_stage, ctxs[0]->device, ranks[i].d_sum, ctxs[i]->device, n_doubles * sizeof(double), ctxs[0]->stream);
+            if (e != hipSuccess) break;
+            hipLaunchKernelGGL(k_merge_tiles, dim3(grid_for(ctxs[0], (size_t)p->width * p->height, 8)), dim3(RT_BLOCK), 0, ctxs[0]->stream,
+                               ranks[0].d_sum, (const double*)d_stage, p->width, p->height, tile, i, n_ctx);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctxs[0]->stream);
+        if (d_stage) hipFree(d_stage);
+        if (e != hipSuccess) { (void)hipGetLastError(); rc = ctx_fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_NO_DEVICE, "render_multi: gather", e); }
+    }
+    if (rc == RT_OK) {
+        hipError_t e = hipSetDevice(ctxs[0]->device);
+        if (e == hipSuccess) e = hipMemcpy(rgb_sum_out, ranks[0].d_sum, n_doubles * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { (void)hipGetLastError(); rc = ctx_fail(ctx, RT_ERR_NO_DEVICE, "render_multi: download framebuffer", e); }
+    }
+    cleanup();
     if (rc == RT_OK && rgb8_out) rt_tonemap(rgb_sum_out, (size_t)p->width * p->height, (double)spp, rgb8_out);
     return rc;
 } RT_ABI_CATCH

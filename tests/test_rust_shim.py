@@ -21,6 +21,9 @@ def c_type_to_rust(t):
     t = re.sub(r"\s+", " ", t.strip())
     t = re.sub(r"\[\d*\]$", "*", t)                     # `const double p[3]` decays to a pointer
     t = t.replace(" *", "*").replace("* ", "*")
+    m = re.fullmatch(r"(\w+)\*const\*", t)              # `rt_context* const* ctxs`: a constant array of mutable pointers
+    if m:
+        return "*const *mut " + m.group(1)
     base_map = {"int": "c_int", "double": "f64", "uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize",
                 "char": "c_char", "void": "c_void"}
     m = re.fullmatch(r"(const )?(\w+)(\**)", t)
