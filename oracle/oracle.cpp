@@ -262,9 +262,54 @@ static size_t f64_as_usize(double v) { // Rust `as usize`
     if (v >= 18446744073709551615.0) return SIZE_MAX;
     return (size_t)v;
 }
+// The uniforms Perlin::init draws while a scene is built. The reference takes them from thread_rng(); here they come from
+// the scene builder's sequential stream, whose definition is restated (not shared): draw number 2c and 2c+1 are words (0,1)
+// and (2,3) of Philox(counter = (c lo, c hi, 0x5EED, stream), key = (seed lo, seed hi)). The constructor log records the
+// stream's position in front of each NoiseTexture, so that the tables below are made here, by this file's own reading of
+// perlin.rs:15-54, and only compared with the ones the product made.
+struct BuildStream {
+    uint64_t seed = 0, counter = 0;
+    uint32_t stream = 0;
+    bool have_spare = false;
+    double spare = 0.0;
+    double next() {
+        if (have_spare) { have_spare = false; return spare; }
+        const U4 o = philox(U4{(uint32_t)counter, (uint32_t)(counter >> 32), 0x5EEDu, stream}, (uint32_t)seed, (uint32_t)(seed >> 32));
+        ++counter;
+        spare = to_unit(o.c, o.d);
+        have_spare = true;
+        return to_unit(o.a, o.b);
+    }
+    double random_double(double low, double high) { return low + (high - low) * next(); }       // rtweekend.rs:19-22
+    int random_int(int low, int high) {                                                          // rtweekend.rs:24-27
+        const int v = low + (int)std::floor(next() * (double)(high - low));
+        return v >= high ? high - 1 : v;
+    }
+};
 struct Perlin {
     std::vector<Vec3> ranvec;
     std::vector<int32_t> perm_x, perm_y, perm_z;
+    static void permut(std::vector<int32_t>& p, int n, BuildStream& rng) { // perlin.rs:28-34: swaps p[i] with an entry of p[0 .. n-i), not of p[0 .. i]
+        for (int i = 1; i < n; ++i) {
+            const size_t target = (size_t)rng.random_int(0, n - i);
+            std::swap(p[(size_t)i], p[target]);
+        }
+    }
+    void perlin_generate_perm(int axis, BuildStream& rng) {                // perlin.rs:15-26
+        std::vector<int32_t>& tmp = axis == 0 ? perm_x : axis == 1 ? perm_y : perm_z;
+        const int point_count = 256;
+        for (int i = 0; i < point_count; ++i) tmp.push_back(i);
+        permut(tmp, point_count, rng);
+    }
+    void init(BuildStream& rng) {                                          // perlin.rs:46-54; Vec3::random_range, vec3.rs:65-71
+        for (int i = 0; i < 256; ++i) {
+            const double x = rng.random_double(-1.0, 1.0), y = rng.random_double(-1.0, 1.0), z = rng.random_double(-1.0, 1.0);
+            ranvec.push_back(Vec3(x, y, z));
+        }
+        perlin_generate_perm(0, rng);
+        perlin_generate_perm(1, rng);
+        perlin_generate_perm(2, rng);
+    }
     static double trilinear_interp(Vec3 c[2][2][2], double u, double v, double w) { // perlin.rs:87-111
         double accum = 0.0;
         double uu = u * u * (3.0 - 2.0 * u);
@@ -307,7 +352,9 @@ struct Perlin {
     }
 };
 struct NoiseTexture : Texture {
-    Perlin noise;
+    Perlin noise;                 // made by Perlin::init above
+    std::vector<double> listed_vec;   // what the constructor log lists (the product's tables): never used to render,
+    std::vector<int32_t> listed_perm; // only handed out for comparison (orc_perlin_tables)
     double scale;
     Color value(double, double, Point3 p) const override { // texture.rs:73-79
         return Color(1.0, 1.0, 1.0) * 0.5 * (1.0 + std::sin(scale * p.z + 10.0 * noise.turb(p, 7)));
@@ -876,10 +923,19 @@ static Scene* load(const char* text, size_t n, uint64_t bvh_seed, bool share_axe
                 int id = I();
                 auto t = std::make_shared<NoiseTexture>();
                 t->scale = D();
-                for (int i = 0; i < 256; ++i) { double x = D(), y = D(), z = D(); t->noise.ranvec.push_back(Vec3(x, y, z)); }
-                for (int i = 0; i < 256; ++i) t->noise.perm_x.push_back(I());
-                for (int i = 0; i < 256; ++i) t->noise.perm_y.push_back(I());
-                for (int i = 0; i < 256; ++i) t->noise.perm_z.push_back(I());
+                for (int i = 0; i < 768; ++i) t->listed_vec.push_back(D());
+                for (int i = 0; i < 768; ++i) t->listed_perm.push_back(I());
+                std::string tag;
+                in >> tag;
+                if (tag != "rng") throw Panic{"tex_noise: the position of the build stream is missing"};
+                BuildStream rng;
+                auto U = [&]() { unsigned long long v; if (!(in >> v)) throw Panic{"short line: " + l.substr(0, 60)}; return (uint64_t)v; };
+                { const uint64_t lo = U(), hi = U(); rng.seed = lo | (hi << 32); }
+                { const uint64_t lo = U(), hi = U(); rng.counter = lo | (hi << 32); }
+                rng.stream = (uint32_t)U();
+                rng.have_spare = I() != 0;
+                rng.spare = D();
+                t->noise.init(rng);
                 sc->tex[id] = t;
             } else if (op == "tex_image") {
                 int id = I(); int w = I(), h = I(); long nb; in >> nb;
@@ -992,6 +1048,19 @@ void* orc_load(const char* text, size_t n, uint64_t bvh_seed, int share_bvh_axes
 }
 void orc_free(void* s) { delete (orc::Scene*)s; }
 uint32_t orc_n_media(void* s) { return ((orc::Scene*)s)->n_media; }
+// The Perlin tables of NoiseTexture `tex_id`: the ones this file's Perlin::init made (vec: 768 doubles, perm: perm_x, perm_y,
+// perm_z, 768 ints) and the ones the constructor log listed. 0 = ok, -1 = no such noise texture.
+int orc_perlin_tables(void* s, int tex_id, double* own_vec, int32_t* own_perm, double* listed_vec, int32_t* listed_perm) {
+    orc::Scene* sc = (orc::Scene*)s;
+    auto it = sc->tex.find(tex_id);
+    if (it == sc->tex.end()) return -1;
+    const orc::NoiseTexture* t = dynamic_cast<const orc::NoiseTexture*>(it->second.get());
+    if (!t) return -1;
+    for (int i = 0; i < 256; ++i) { own_vec[3 * i] = t->noise.ranvec[(size_t)i].x; own_vec[3 * i + 1] = t->noise.ranvec[(size_t)i].y; own_vec[3 * i + 2] = t->noise.ranvec[(size_t)i].z; }
+    for (int i = 0; i < 256; ++i) { own_perm[i] = t->noise.perm_x[(size_t)i]; own_perm[256 + i] = t->noise.perm_y[(size_t)i]; own_perm[512 + i] = t->noise.perm_z[(size_t)i]; }
+    for (int i = 0; i < 768; ++i) { listed_vec[i] = t->listed_vec[(size_t)i]; listed_perm[i] = t->listed_perm[(size_t)i]; }
+    return 0;
+}
 
 // world.hit for a batch of rays (hittable_list.rs:40-53). counts (nullable): 7 uint64 as in orc_stats order
 // from node_tests on, summed over the batch.

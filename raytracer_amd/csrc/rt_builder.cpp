@@ -1421,6 +1421,7 @@ int rt_tex_checker(rt_builder* b, int even_tex, int odd_tex) try {
 int rt_tex_noise(rt_builder* b, double scale) try {
     if (!b) return RT_ERR_INVALID;
     TexRec t; t.type = RT_TEX_NOISE; t.p[0] = scale;
+    const SeqRng before = b->rng; // where the build stream stands: logged, so that a reader of the log can make the tables itself
     // Perlin::init (perlin.rs:46-54): 256 un-normalised gradients from random_range(-1,1), then three
     // permutations, each shuffled by `for i in 1..n { swap(p[i], p[random_int(0, n-i)]) }` (perlin.rs:28-34)
     t.perlin_vec.resize(RT_PERLIN_POINTS * 3);
@@ -1440,7 +1441,8 @@ int rt_tex_noise(rt_builder* b, double scale) try {
     log_fmt(b->log, "tex_noise %d %a", id, scale);
     for (double v : b->texs.back().perlin_vec) log_fmt(b->log, " %a", v);
     for (int32_t v : b->texs.back().perlin_perm) log_fmt(b->log, " %d", v);
-    log_fmt(b->log, "\n");
+    log_fmt(b->log, " rng %u %u %u %u %u %d %a\n", (unsigned)(before.seed & 0xFFFFFFFFu), (unsigned)(before.seed >> 32),
+            (unsigned)(before.counter & 0xFFFFFFFFu), (unsigned)(before.counter >> 32), before.stream, before.have_spare ? 1 : 0, before.spare);
     return id;
 } RT_ABI_CATCH
 int rt_tex_image(rt_builder* b, const uint8_t* rgb8, uint32_t width, uint32_t height) try {

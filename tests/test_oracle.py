@@ -360,7 +360,7 @@ class PerlinByHand:
         line = [l for l in desc.split(b"\n") if l.startswith(b"tex_noise %d " % tex_id)][0].split()
         self.scale = float.fromhex(line[2].decode())
         self.vec = np.array([float.fromhex(v.decode()) for v in line[3:3 + 768]]).reshape(256, 3)
-        perm = np.array([int(v) for v in line[3 + 768:]]).reshape(3, 256)
+        perm = np.array([int(v) for v in line[3 + 768:3 + 768 + 768]]).reshape(3, 256)     # (behind them: the build stream's position)
         assert all(sorted(perm[a].tolist()) == list(range(256)) for a in range(3))   # three permutations
         assert np.all(np.abs(self.vec) <= 1.0)
         self.perm = perm

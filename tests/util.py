@@ -20,6 +20,17 @@ def build_scene(name, n=None, flags=0):
     return b, info, b.compile(info.world), b.describe(info.world)
 
 
+SECTIONS = ("nodes", "spheres", "sphere_meta", "mspheres", "msphere_meta", "rects", "rect_meta", "boxes", "box_meta", "media", "insts",
+            "list_entries", "materials", "textures", "perlin_vec", "perlin_perm", "texels", "exact_boxes", "chains")
+
+
+def blob_header(blob):
+    """{section name: (byte offset, element count)} of a compiled scene blob (RtBlobHeader: 96 bytes of scalars, then the
+    section table in the order of SECTIONS)."""
+    secs = np.frombuffer(blob, dtype="<u8", count=len(SECTIONS) * 2, offset=96).reshape(len(SECTIONS), 2)
+    return {name: (int(secs[i, 0]), int(secs[i, 1])) for i, name in enumerate(SECTIONS)}
+
+
 def rays_from(o, d, time=0.0, tmin=0.001, tmax=np.inf):
     o = np.atleast_2d(np.asarray(o, dtype=np.float64))
     d = np.atleast_2d(np.asarray(d, dtype=np.float64))
