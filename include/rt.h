@@ -261,6 +261,12 @@ int rt_render_multi(rt_context* const* ctxs, uint32_t n_ctx, const void* blob, s
 /* main.rs:172-189 on the host for an already gathered sum buffer */
 void rt_tonemap(const double* rgb_sum, size_t n_pixels, double spp, uint8_t* rgb8_out);
 
+/* The reference's own Vec3 assertions (vec3.rs:259-399: twenty known answers in a commented-out test module - add, sub,
+ * scalar forms, mul, div, cross, neg, squared_length, length, unit, and the zero-length unit() that panics there and is
+ * the zero vector here), evaluated by one lane of the device on the vector type the kernels use. *failed = one bit per
+ * assertion that did not hold, in the module's order; 0 = all hold. */
+int rt_selftest_vec3(rt_context*, uint32_t* failed);
+
 /* Device memory for callers without their own allocator (freed by rt_device_free). */
 int rt_device_alloc(rt_context*, size_t nbytes, void** d_ptr);
 int rt_device_free(rt_context*, void* d_ptr);

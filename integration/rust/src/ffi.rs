@@ -180,6 +180,7 @@ extern "C" {
     pub fn rt_device_count() -> c_int;
     pub fn rt_render_multi(ctxs: *const *mut rt_context, n_ctx: u32, blob: *const c_void, nbytes: usize, camera: *const rt_camera, params: *const rt_params, spp: u32, rgb_sum_out: *mut f64, rgb8_out: *mut u8, stats: *mut rt_stats) -> c_int;
     pub fn rt_tonemap(rgb_sum: *const f64, n_pixels: usize, spp: f64, rgb8_out: *mut u8);
+    pub fn rt_selftest_vec3(ctx: *mut rt_context, failed: *mut u32) -> c_int;
     pub fn rt_device_alloc(ctx: *mut rt_context, nbytes: usize, d_ptr: *mut *mut c_void) -> c_int;
     pub fn rt_device_free(ctx: *mut rt_context, d_ptr: *mut c_void) -> c_int;
     pub fn rt_device_memset(ctx: *mut rt_context, d_ptr: *mut c_void, value: c_int, nbytes: usize) -> c_int;

@@ -115,6 +115,7 @@ PROTOTYPES = {
     "rt_render_multi": (C.c_int, [C.POINTER(_P), C.c_uint32, _P, C.c_size_t, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_uint32, _P, _P,
                                   C.POINTER(rt_stats)]),
     "rt_tonemap": (None, [_P, C.c_size_t, C.c_double, _P]),
+    "rt_selftest_vec3": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "rt_device_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "rt_device_free": (C.c_int, [_P, _P]),
     "rt_device_memset": (C.c_int, [_P, _P, C.c_int, C.c_size_t]),

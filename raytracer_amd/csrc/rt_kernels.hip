@@ -884,6 +884,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_camera_rays(RtCameraDev cam, uint3
     }
 }
 
+__global__ void k_vec3_kat(double one, uint32_t* failed) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *failed = rt_vec3_kat(one);
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------
 // rt_trace_first_hit_noalloc: everything rt_trace_first_hit gets from hipMalloc - the staging copies of the caller's rays,
 // uniforms and hit records, and the word the kernel raises on a stack overflow - lives in this array instead. Every GPU
@@ -1649,6 +1653,23 @@ int rt_render(rt_context* ctx, const rt_scene* sc, const rt_camera* cam, const r
     hipFree(d_sum);
     if (rc == RT_OK && rgb8_out) rt_tonemap(rgb_sum_out, (size_t)p->width * p->height, (double)spp, rgb8_out);
     return rc;
+} RT_ABI_CATCH
+
+int rt_selftest_vec3(rt_context* ctx, uint32_t* failed) try {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!failed) return ctx_fail(ctx, RT_ERR_INVALID, "selftest_vec3: null argument");
+    RT_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    uint32_t* d = nullptr;
+    RT_HIP(hipMalloc((void**)&d, sizeof(uint32_t)), "hipMalloc");
+    volatile double one = 1.0; // (read at run time: the kernel must do the arithmetic, not the compiler)
+    hipLaunchKernelGGL(k_vec3_kat, dim3(1), dim3(64), 0, ctx->stream, (double)one, d);
+    hipError_t e = hipGetLastError();
+    *failed = 0xFFFFFFFFu;
+    if (e == hipSuccess) e = hipMemcpyAsync(failed, d, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d);
+    if (e != hipSuccess) { (void)hipGetLastError(); return ctx_fail(ctx, RT_ERR_NO_DEVICE, "selftest_vec3", e); }
+    return RT_OK;
 } RT_ABI_CATCH
 
 int rt_device_count(void) {

@@ -176,3 +176,38 @@ RT_HD V3 rt_random_in_unit_sphere(const Sampler& s) {
     return p;
 }
 RT_HD V3 rt_random_unit_vector(const Sampler& s) { return v3_unit(rt_random_in_unit_sphere(s)); } // vec3.rs:82-84
+
+// The reference's own Vec3 assertions (raytracer/src/vec3.rs:259-399, a commented-out test module: the only known answers
+// the reference holds), replayed on V3. `one` must be 1.0 and come from where the compiler cannot see it (a kernel
+// argument, a caller's variable), so that the arithmetic runs on the machine under test instead of being folded away.
+// Returns a bit per failed assertion, in the order of the module; 0 = all twenty hold.
+RT_HD uint32_t rt_vec3_kat(double one) {
+    uint32_t failed = 0u, k = 0u;
+    const auto same = [](V3 a, V3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; };
+    const auto expect = [&](bool ok) { if (!ok) failed |= 1u << k; ++k; };
+    const auto mk = [&](double x, double y, double z) { return v3(x * one, y * one, z * one); };
+    const auto splat = [&](double s) { return v3(s * one, s * one, s * one); };       // Vec3 (+|-) f64: vec3.rs:125-155, 169-199
+    expect(same(mk(1.0, 2.0, 3.0), v3(1.0, 2.0, 3.0)));                                                     // test_new
+    expect(same(mk(1.0, 0.0, -1.0) + mk(2.0, 4.0, 6.0), v3(3.0, 4.0, 5.0)));                                // test_add
+    { V3 x = mk(1.0, 0.0, -1.0); x = x + mk(2.0, 4.0, 6.0); expect(same(x, v3(3.0, 4.0, 5.0))); }           // test_add_assign
+    expect(same(mk(1.0, 0.0, -1.0) + splat(233.0), v3(234.0, 233.0, 232.0)));                               // test_add_f64
+    { V3 x = mk(1.0, 0.0, -1.0); x = x + splat(233.0); expect(same(x, v3(234.0, 233.0, 232.0))); }          // test_add_assign_f64
+    expect(same(mk(1.0, 0.0, -1.0) - mk(2.0, 4.0, 6.0), v3(-1.0, -4.0, -7.0)));                             // test_sub
+    { V3 x = mk(1.0, 0.0, -1.0); x = x - mk(2.0, 4.0, 6.0); expect(same(x, v3(-1.0, -4.0, -7.0))); }        // test_sub_assign
+    expect(same(mk(1.0, 0.0, -1.0) - splat(1.0), v3(0.0, -1.0, -2.0)));                                     // test_sub_f64
+    { V3 x = mk(1.0, 0.0, -1.0); x = x - splat(1.0); expect(same(x, v3(0.0, -1.0, -2.0))); }                // test_sub_assign_f64
+    { V3 x = mk(1.0, 0.0, -1.0); x = x * (2.0 * one); expect(same(x, v3(2.0, 0.0, -2.0))); }                // test_mul_assign
+    expect(same(mk(1.0, 0.0, -1.0) * (1.0 * one), v3(1.0, 0.0, -1.0)));                                     // test_mul_f64
+    expect(same(mk(1.0, -2.0, 0.0) / (2.0 * one), v3(0.5, -1.0, 0.0)));                                     // test_div
+    expect(same(v3_cross(mk(1.0, 2.0, 3.0), mk(2.0, 3.0, 4.0)), v3(8.0 - 9.0, 6.0 - 4.0, 3.0 - 4.0)));      // test_cross
+    expect(same(-mk(1.0, -2.0, 3.0), v3(-1.0, 2.0, -3.0)));                                                 // test_neg
+    expect(v3_sqlen(mk(1.0, 2.0, 3.0)) == 14.0);                                                            // test_squared_length
+    expect(v3_len(mk(3.0, 4.0, 5.0)) == sqrt(3.0 * 3.0 + 4.0 * 4.0 + 5.0 * 5.0));                           // test_length
+    expect(same(v3_unit(mk(233.0, 0.0, 0.0)), v3(1.0, 0.0, 0.0)));                                          // test_unit, first
+    expect(same(v3_unit(mk(-233.0, 0.0, 0.0)), v3(-1.0, 0.0, 0.0)));                                        // test_unit, second
+    // test_unit_panic: the reference panics on a zero vector ("div 0!", vec3.rs:52); nothing may trap on the device, so the
+    // defined result here is the zero vector - and the condition the panic tests is still what decides it
+    expect(v3_len(mk(0.0, 0.0, 0.0)) == 0.0);
+    expect(same(v3_unit(mk(0.0, 0.0, 0.0)), v3(0.0, 0.0, 0.0)));
+    return failed;
+}

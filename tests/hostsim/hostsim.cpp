@@ -247,4 +247,7 @@ void hs_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
     for (int i = 0; i < 4; ++i) out[i] = o.v[i];
 }
 
+
+// The reference's Vec3 assertions (vec3.rs:259-399) on the product's own vector type, evaluated here on the CPU.
+uint32_t hs_vec3_kat(double one) { return rt_vec3_kat(one); }
 } // extern "C"

@@ -314,3 +314,14 @@ def test_empty_worlds():
             assert segments == 16 * 12 * 3 and np.array_equal(got[0, 0], 3 * np.array([0.25, 0.5, 1.0]))   # every ray: the background
         hit, _ = ck.hostsim_trace_first_hit(blob, rays)
         assert np.array_equal(hit["prim_id"], osc.trace_first_hit(rays)["prim_id"]) and hit["prim_id"][1] == MISS
+
+
+def test_the_references_vec3_assertions_hold_on_the_products_vector_type():
+    """vec3.rs:259-399 - twenty known answers in a commented-out test module, the only ones the reference holds - replayed
+    on V3 of raytracer_amd/csrc/rt_math.h as the host compiler builds it (the GPU suite runs the same function on the device)."""
+    import ctypes as C
+    h = ck.hostsim()
+    h.hs_vec3_kat.restype = C.c_uint32
+    h.hs_vec3_kat.argtypes = [C.c_double]
+    assert h.hs_vec3_kat(1.0) == 0
+    assert h.hs_vec3_kat(1.0000001) != 0     # (the check does look at the values: a scale factor breaks the equalities)

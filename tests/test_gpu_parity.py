@@ -292,6 +292,41 @@ def test_gate2_converged_image(gpu_ctx):
     scene.close()
 
 
+@pytest.mark.parametrize("name,share_axes", [("random_scene", False), ("cornell_box", True), ("stress_volume", False), ("my_scene", False)])
+def test_gate2_converged_image_of_the_other_configurations(gpu_ctx, name, share_axes):
+    """The same gate at 4096 spp, 48x48, for the Book-1 scene, the Cornell box, the texture / volume stress scene and the
+    reference's live scene. The oracle builds its own BVHs (its own random split axes) wherever the image does not depend
+    on them; under the Cornell box's BvhNode sit RotateY objects whose boxes the reference never rotates
+    (hittable.rs:117-143), so what gets clipped there depends on the axes, and the oracle replays the product's."""
+    import time
+    _, info, blob, desc = util.build_scene(name)
+    osc = ck.OracleScene(desc, share_bvh_axes=share_axes)
+    scene = gpu_ctx.upload(blob)
+    p = api.params_from_info(info, width=48, height=48, seed=util.RENDER_SEED)
+    spp = 4096
+    got = gpu_ctx.render(scene, info.camera, p, spp) / spp
+    t0 = time.time()
+    want = osc.render(info.camera, p, spp)[0] / spp
+    lum_g, lum_w = util.luminance(got).mean(), util.luminance(want).mean()
+    rmse = float(np.sqrt(np.mean((np.sqrt(np.clip(got, 0, 1)) - np.sqrt(np.clip(want, 0, 1))) ** 2)))
+    print("\n%s 48x48 @ %d spp: luminance gpu %.6f oracle %.6f (ratio %.6f), rmse of sqrt-mapped mean %.3e; oracle %.1f s" %
+          (name, spp, lum_g, lum_w, lum_g / lum_w, rmse, time.time() - t0))
+    assert abs(lum_g / lum_w - 1.0) <= 0.005
+    assert rmse <= 0.01
+    scene.close()
+
+
+def test_the_references_vec3_assertions_hold_on_the_device(gpu_ctx):
+    """vec3.rs:259-399, the twenty known answers the reference holds, evaluated by a lane of the GPU on the kernels' own
+    vector type (the oracle replays them for itself: tests/test_oracle.py; the host build of the same type:
+    tests/test_device_code_on_cpu.py)."""
+    import ctypes as C
+    from raytracer_amd import _lib
+    failed = C.c_uint32(0xFFFFFFFF)
+    assert _lib.lib.rt_selftest_vec3(gpu_ctx._c, C.byref(failed)) == 0
+    assert failed.value == 0, "assertions that failed (bit = position in the module): %#x" % failed.value
+
+
 def test_results_do_not_depend_on_pass_size_tiles_or_rank_count(gpu_ctx):
     _, info, blob, _ = util.build_scene("final_scene")
     scene = gpu_ctx.upload(blob)
