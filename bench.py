@@ -79,7 +79,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(desc, info, seed, target_seconds):
+def cpu_baseline(desc, info, seed, target_seconds, scene_name="final_scene"):
     """The oracle (a restatement of the reference's CPU renderer, not the Rust binary) timed on ALL of this host's
     cores over a bounded sample of the same workload: whole 800x800 image, as many spp as fit in about target_seconds."""
     native = native_oracle()
@@ -101,7 +101,7 @@ def cpu_baseline(desc, info, seed, target_seconds):
                  "g++ -O3 -ffp-contract=off (generic x86-64 build shipped with the tree; no compiler on this host)",
         "samples_per_sec": st.camera_samples / st.seconds,
         "sample": "oracle (C++ f64 restatement of the reference renderer, not the Rust binary; %d threads, %d row-band jobs), "
-                  "final_scene %dx%d, %d spp, depth %d: %.1f s" % (st.threads, st.jobs, info.width, info.height, spp, info.max_depth, st.seconds),
+                  "%s %dx%d, %d spp, depth %d: %.1f s" % (st.threads, st.jobs, scene_name, info.width, info.height, spp, info.max_depth, st.seconds),
         "reference_default": {"value": st2.ray_segments / st2.seconds, "unit": "rays/s", "cores": 2,
                               "sample": "the same with the reference's default 2 workers / 16 jobs, 1 spp: %.1f s" % st2.seconds},
     }
@@ -116,7 +116,7 @@ def launch_ranks(world):
     if have < world:
         raise SystemExit("bench.py --gpus %d needs %d GPUs on this machine; it has %d" % (world, world, have))
     from raytracer_amd import dist as rdist
-    rc, codes = rdist.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], world)
+    rc, codes = rdist.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], world, timeout=float(os.environ.get("RT_BENCH_TIMEOUT", "3300")))
     if rc != 0:
         print("bench.py: rank exit codes %s" % codes, file=sys.stderr)
     sys.exit(rc if 0 <= rc < 256 else 1)
@@ -128,7 +128,16 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp", type=int, default=1536, help="samples per pixel per GPU per step (reduced - 1536, 1024, 512, ... - until the path state fits the GPU)")
-    ap.add_argument("--scene", default="final_scene")
+    ap.add_argument("--scene", default="final_scene", help="final_scene (the metric's configuration), cornell_box, random_scene, stress_volume, "
+                                                           "spheres_grid, my_scene, cornell_smoke, ...")
+    ap.add_argument("--n", type=int, default=0, help="object count of scaled scenes (spheres_grid: default 1 000 000)")
+    # the workload constants of the reference's main() (main.rs:75-79) and the render's own switches
+    ap.add_argument("--width", type=int, default=0, help="image width (default: the scene's own configuration)")
+    ap.add_argument("--height", type=int, default=0, help="image height")
+    ap.add_argument("--depth", type=int, default=0, help="max_depth (main.rs:79; default: the scene's, 50)")
+    ap.add_argument("--seed", type=lambda v: int(v, 0), default=0x5EED0002, help="render seed (Philox key material)")
+    ap.add_argument("--compat", type=int, default=0, help="bit 0: book-correct RotateY back-rotation, bit 1: book-correct XY lens disk "
+                                                          "(default 0: as the reference computes them)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="every rank renders on cuda:0 and the collectives run over gloo: the N-rank code path (launch, "
@@ -161,13 +170,13 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    scene_seed, render_seed = 0x5EED0001, 0x5EED0002
+    scene_seed, render_seed = 0x5EED0001, args.seed
     ctx = api.Context(local_rank)
     desc = None
     if rank == 0:
         b = api.Builder(seed=scene_seed)
         b.register_reference_textures(tuple(api.TEXTURE_FILES) if args.scene == "my_scene" else ("earthmap.jpg",))
-        info = b.named_scene(args.scene, scene_seed)
+        info = b.named_scene(args.scene, scene_seed, args.n)
         blob = b.compile(info.world)
         desc = b.describe(info.world)
     if world > 1:
@@ -176,11 +185,15 @@ def main():
         if rank != 0:
             b = api.Builder(seed=scene_seed)
             b.register_reference_textures(tuple(api.TEXTURE_FILES) if args.scene == "my_scene" else ("earthmap.jpg",))
-            info = b.named_scene(args.scene, scene_seed)
+            info = b.named_scene(args.scene, scene_seed, args.n)
         scene = ctx.upload_from_device(buf.data_ptr(), buf.numel())
     else:
         scene = ctx.upload(blob)
 
+    if args.width or args.height:
+        info.width, info.height = args.width or info.width, args.height or info.height
+    if args.depth:
+        info.max_depth = args.depth
     W, H = info.width, info.height
     # One step = one pass of spp_step samples per pixel: the 50 bounces of a pass are 50 dependent rounds of launches, each
     # with a latency floor, so a pass is made as large as the HBM takes (232 B of path state per path: 1536 spp of this
@@ -188,7 +201,7 @@ def main():
     while True:
         spp_step = args.spp * world
         params = api.params_from_info(info, seed=render_seed, tile=rdist.DEFAULT_TILE, tile_rank=rank, tile_world=world,
-                                      spp_per_pass=spp_step, profile=1)
+                                      spp_per_pass=spp_step, profile=1, compat=args.compat)
         d_sum = torch.zeros(W * H * 3, dtype=torch.float64, device=device)
         torch.cuda.synchronize()  # the library launches on its own stream: the buffer must be zeroed before it is handed over
         fits = torch.ones(1, dtype=torch.int32, device=device)
@@ -246,25 +259,33 @@ def main():
         achieved = EXTEND_BYTES_PER_SEGMENT * seg_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         ref_work = reference_work_per_segment(args.scene)
         rate = segments / elapsed / world  # per GPU
-        # Counters cannot be read inside this process: they come from rocprofv3 --pmc runs of tools/gpu_round.sh, kept in
-        # profiles/ with the pass size they were taken at (counters_from).
-        traffic, counters_from = None, {}
-        pmc_path = os.path.join(ROOT, "profiles", "extend_hbm_traffic.json")
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
+        # Counters cannot be read inside this process: they come from rocprofv3 --pmc runs (tools/gpu_profile.sh), kept in
+        # profiles/ with the scene, image and pass size they were taken at (counters_from). They are quoted only for the
+        # workload they were measured on: another scene or image size gets null, not Book-2's figures.
+        def counters_of(path):
+            if not os.path.exists(path):
+                return None
+            j = json.load(open(path))
+            same = (j.get("scene", "final_scene") == args.scene and j.get("width", 800) == W and j.get("height", 800) == H and
+                    j.get("max_depth", 50) == info.max_depth and args.compat == 0)
+            return j if same else None
+        traffic, counters_from, valu = None, {}, None
+        pmc = counters_of(os.path.join(ROOT, "profiles", "extend_hbm_traffic.json"))
+        if pmc:
             traffic = pmc.get("hbm_bytes_per_launch_corrected")
             counters_from["traffic"] = {"file": "profiles/extend_hbm_traffic.json", "spp_per_pass": pmc.get("spp_per_pass"),
                                         "segments_per_launch": pmc.get("segments_per_launch"),
                                         "correction": "FETCH_SIZE x 2 (gfx950, 16-byte-per-lane streaming reads) + WRITE_SIZE"}
-        valu = {}
-        sq_path = os.path.join(ROOT, "profiles", "sq_counters.json")  # rocprofv3 --pmc SQ_* passes (tools/sq_summary.py)
-        if os.path.exists(sq_path):
-            sqj = json.load(open(sq_path))
+        sqj = counters_of(os.path.join(ROOT, "profiles", "sq_counters.json"))  # rocprofv3 --pmc SQ_* passes (tools/profile_summary.py)
+        if sqj:
             sq = sqj.get("k_extend_tree", {})
             if sq.get("valu_busy") is not None and sq.get("lane_use") is not None:
-                valu = {"valu_busy": sq["valu_busy"], "valu_lane_use": sq["lane_use"],
-                        "valu_useful_issue_frac": sq["valu_busy"] * sq["lane_use"]}
+                # the bound this kernel runs against: the share of the vector unit's issue slots that do useful lanes
+                valu = {"busy": sq["valu_busy"], "lane_use": sq["lane_use"], "frac": sq["valu_busy"] * sq["lane_use"],
+                        "unit": "share of VALU issue slots x lanes (1 = every SIMD issues a full-width instruction every 4 cycles)"}
             counters_from["valu"] = {"file": "profiles/sq_counters.json", "spp_per_pass": sqj.get("spp_per_pass")}
+        if not counters_from:
+            counters_from = {"note": "no rocprofv3 counters are kept for this scene / image size / depth: traffic and valu are null"}
         out = {
             "metric": "rays_per_sec", "value": segments / elapsed, "unit": "rays/s",
             "samples_per_sec": samples / elapsed,
@@ -272,7 +293,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s, %dx%d, max depth %d, %d spp per step (%d per GPU), scene seed 0x5EED0001, render seed 0x5EED0002" %
                                    ("Book-2 final scene (final_scene, main.rs:576-688)" if args.scene == "final_scene" else "scene " + args.scene,
-                                    W, H, info.max_depth, spp_step, args.spp),
+                                    W, H, info.max_depth, spp_step, args.spp) + (", render seed %#x" % render_seed if render_seed != 0x5EED0002 else "") +
+                                   (", compat %d" % args.compat if args.compat else ""),
                        "scene": args.scene, "width": W, "height": H, "spp_per_step": spp_step, "max_depth": info.max_depth,
                        "tile": rdist.DEFAULT_TILE, "sharding": "tiles round-robin over %d rank(s)" % world},
             "rays_per_sample": segments / samples,
@@ -283,16 +305,17 @@ def main():
                 # peak (measured here). The kernel is not bound by HBM: the scene sits in L2 / LDS, and what limits it is
                 # the vector unit under divergence - valu_busy x valu_lane_use, from the SQ counters (counters_from) - and the
                 # chain of dependent steps a wave runs per node and leaf, with four waves per SIMD to overlap them.
-                "kernel": "k_extend_tree", "bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "k_extend_tree", "bound": "valu", "valu": valu,
+                # the HBM side, as the bench contract states it (achieved / peak / frac are HBM figures, not the bound's):
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "frac_of": "hbm", "traffic": traffic,
                 "bytes_per_segment": EXTEND_BYTES_PER_SEGMENT, "segments_per_launch": seg_per_launch,
-                "avg_launch_ms": avg_ms, "launches": int(stats.extend_launches), **valu,
+                "avg_launch_ms": avg_ms, "launches": int(stats.extend_launches),
                 "counters_from": counters_from,
-                "note": "cache-resident scene: bound by VALU issue and the latency of each wave's dependent steps under "
-                        "divergence (valu_busy counts every instruction as 4 cycles; valu_busy x valu_lane_use = the share "
-                        "of VALU issue slots doing useful lanes), not by HBM; achieved/frac "
-                        "are the compulsory path-state bytes against the HBM peak; traffic = HBM bytes per launch from "
-                        "FETCH_SIZE x 2 + WRITE_SIZE at the pass size named in counters_from",
+                "note": "bound by VALU issue and the latency of each wave's dependent steps under divergence, not by HBM: "
+                        "valu.busy counts every vector instruction as 4 SIMD cycles, valu.frac = busy x lane_use is the figure "
+                        "for the stated bound; achieved / peak / frac are the kernel's compulsory path-state bytes against "
+                        "the HBM peak; traffic = HBM bytes per launch from FETCH_SIZE x 2 + WRITE_SIZE at the pass size named in "
+                        "counters_from; valu and traffic are null when no counters are kept for this workload",
             },
             "path_hbm_frac": PATH_BYTES_PER_SEGMENT * rate / 1e9 / HBM_PEAK_GBS,
             # the same rate priced in the reference traversal's arithmetic and scene reads (the GPU path does less of both)
@@ -306,7 +329,7 @@ def main():
                           "shade_textured_isotropic": stats.shade_ms[4]},
         }
         if args.cpu_seconds > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(desc, info, render_seed, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(desc, info, render_seed, args.cpu_seconds, args.scene)
         print(json.dumps(out), flush=True)
 
     scene.close()

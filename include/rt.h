@@ -54,6 +54,11 @@ const char* rt_builder_last_error(const rt_builder*);
  * bit 3 = the world's tree is left to the device: rt_builder_compile puts the leaves under a balanced stand-in tree
  * (correct, but slow to walk) instead of searching for good splits, and rt_scene_build_tree_device arranges them after the
  * upload. Ignored together with bit 1 and for worlds that hold a BvhNode whose boxes do not bound their contents.
+ * With bit 3 rt_bvh keeps only a node's box and forgets its members' order, so a scene that turns out to need the
+ * reference's order of tests everywhere - one holding a moving sphere with time0 == time1 (every ray "hits" it at
+ * t = NaN), or a medium of density < 0 - must create that object BEFORE the rt_bvh calls it affects: created after
+ * them, rt_builder_compile returns RT_ERR_UNSUPPORTED (the reference-shaped trees can no longer be made). Without bit 3
+ * the order of creation does not matter.
  * Default 0. */
 int rt_builder_set_flags(rt_builder*, uint32_t flags);
 

@@ -20,15 +20,23 @@ import torch.distributed as dist
 DEFAULT_TILE = 32
 
 
-def spawn_ranks(script, argv, world, extra_env=None, grace=30.0):
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(script, argv, world, extra_env=None, grace=30.0, timeout=3300.0):
     """One fresh child process per rank running `script argv...` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
     MASTER_PORT set the way torch.distributed.run sets them (rendezvous on 127.0.0.1, a free port). The children inherit
     stdout and stderr, so what rank 0 prints is what the caller's caller reads. Returns the worst exit code. When a
     rank fails the others may wait for it in a collective for ever: they get `grace` seconds, then are ended (by pid).
+    When no rank fails but none finishes either - every rank stuck in the rendezvous or in a collective - the wait ends
+    after `timeout` seconds all told: the children are ended by pid and the call returns 124, as timeout(1) would.
     The caller must not have initialised a GPU: the children are started with fork + exec."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
+    started = time.monotonic()
+    timed_out = False
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
@@ -39,12 +47,17 @@ def spawn_ranks(script, argv, world, extra_env=None, grace=30.0):
     while any(p.poll() is None for p in procs):
         if failed_at is None and any(p.returncode not in (None, 0) for p in procs):
             failed_at = time.monotonic()
-        if failed_at is not None and time.monotonic() - failed_at > grace:
+        if timeout is not None and not timed_out and time.monotonic() - started > timeout:
+            timed_out = True
+            print("spawn_ranks: no result after %.0f s; ending the %d rank processes" % (timeout, world), file=sys.stderr)
+        if timed_out or (failed_at is not None and time.monotonic() - failed_at > grace):
             for p in procs:
                 if p.poll() is None:
                     p.kill()
         time.sleep(0.05)
     codes = [p.returncode for p in procs]
+    if timed_out:
+        return 124, codes
     bad = [c for c in codes if c != 0]
     return (max(bad, key=abs) if bad else 0), codes
 

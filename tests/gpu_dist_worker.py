@@ -41,7 +41,8 @@ def rccl_one_rank(ctx):
     import torch.distributed as dist
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29641", rank=0, world_size=1, device_id=dev)
+    from raytracer_amd.dist import free_port
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % free_port(), rank=0, world_size=1, device_id=dev)
     try:
         assert dist.get_world_size() == 1 and dist.get_backend() == "nccl"
         _, info, blob, _ = util.build_scene("cornell_box")
