@@ -270,20 +270,26 @@ def main():
                     j.get("max_depth", 50) == info.max_depth and args.compat == 0)
             return j if same else None
         traffic, counters_from, valu = None, {}, None
-        pmc = counters_of(os.path.join(ROOT, "profiles", "extend_hbm_traffic.json"))
+        def first_of(*names):  # per-scene files (tools/gpu_profile_config.sh), then the bench scene's (tools/gpu_profile.sh)
+            for nm in names:
+                j = counters_of(os.path.join(ROOT, "profiles", nm))
+                if j:
+                    return nm, j
+            return None, None
+        pmc_name, pmc = first_of(args.scene + "_extend_hbm_traffic.json", "extend_hbm_traffic.json")
         if pmc:
             traffic = pmc.get("hbm_bytes_per_launch_corrected")
-            counters_from["traffic"] = {"file": "profiles/extend_hbm_traffic.json", "spp_per_pass": pmc.get("spp_per_pass"),
+            counters_from["traffic"] = {"file": "profiles/" + pmc_name, "spp_per_pass": pmc.get("spp_per_pass"),
                                         "segments_per_launch": pmc.get("segments_per_launch"),
                                         "correction": "FETCH_SIZE x 2 (gfx950, 16-byte-per-lane streaming reads) + WRITE_SIZE"}
-        sqj = counters_of(os.path.join(ROOT, "profiles", "sq_counters.json"))  # rocprofv3 --pmc SQ_* passes (tools/profile_summary.py)
+        sq_name, sqj = first_of(args.scene + "_sq_counters.json", "sq_counters.json")  # rocprofv3 --pmc SQ_* passes
         if sqj:
             sq = sqj.get("k_extend_tree", {})
             if sq.get("valu_busy") is not None and sq.get("lane_use") is not None:
                 # the bound this kernel runs against: the share of the vector unit's issue slots that do useful lanes
                 valu = {"busy": sq["valu_busy"], "lane_use": sq["lane_use"], "frac": sq["valu_busy"] * sq["lane_use"],
                         "unit": "share of VALU issue slots x lanes (1 = every SIMD issues a full-width instruction every 4 cycles)"}
-            counters_from["valu"] = {"file": "profiles/sq_counters.json", "spp_per_pass": sqj.get("spp_per_pass")}
+            counters_from["valu"] = {"file": "profiles/" + sq_name, "spp_per_pass": sqj.get("spp_per_pass")}
         if not counters_from:
             counters_from = {"note": "no rocprofv3 counters are kept for this scene / image size / depth: traffic and valu are null"}
         out = {
