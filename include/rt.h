@@ -161,9 +161,10 @@ typedef struct {
                                   bit 1: book-correct XY lens disk (else vec3.rs:105 / camera.rs:58 as written) */
     uint32_t tile;             /* tile edge in pixels for multi-GPU sharding; 0 = default 32 */
     uint32_t tile_rank, tile_world; /* this context renders tiles k with k % tile_world == tile_rank; world 0/1 = everything */
-    uint32_t spp_per_pass;     /* camera samples per pixel traced together; 0 = choose from the path budget (8 M paths). A pass holds
-                                  232 bytes of device memory per path (this context's pixels x spp_per_pass) and runs faster the larger
-                                  it is: its bounces are dependent rounds of launches; RT_ERR_OOM if it does not fit */
+    uint32_t spp_per_pass;     /* camera samples per pixel traced together. A pass holds 232 bytes of device memory per path (this
+                                  context's pixels x spp_per_pass) and runs faster the larger it is: its bounces are dependent rounds
+                                  of launches. 0 = as many as the job has, up to seven eighths of the device memory that is free
+                                  (halved while the allocation fails); a given value is taken as is: RT_ERR_OOM if it does not fit */
     uint32_t profile;          /* 1 = bracket every kernel launch with HIP events (fills the *_ms fields) */
     uint32_t pad;
 } rt_params;

@@ -45,6 +45,7 @@ static_assert(RT_BLOCK % 64 == 0, "kernels hand data from lane to lane inside 64
 #define RT_TREE_BLOCK 1024 /* k_extend_tree: one workgroup per CU, so that the whole CU shares one LDS copy of the top of the tree */
 #define RT_COUNTER_STRIDE 16u /* per iteration: [0] paths entering it at the front of the arrays, [1+q] hits in queue q, [RT_COUNTER_BACK] paths entering it at the back */
 #define RT_COUNTER_BACK 15u
+#define RT_PATH_BYTES 232u /* device memory per path of a pass: two 64-byte ray records, two 24-byte throughputs, 24 bytes of radiance, a 16-byte hit record, four queue words */
 
 // ---- device structures ------------------------------------------------------------------------------------
 // Path state. The paths alive at a bounce are DENSE: path number i of the bounce owns record i of the bounce's ray,
@@ -1511,11 +1512,27 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
     if (rc != RT_OK) return rc;
     const uint32_t n_local = ctx->pm_n;
     if (n_local == 0 || spp == 0) return RT_OK;
-    const size_t budget = (size_t)1 << 23;
-    uint32_t S = p->spp_per_pass ? p->spp_per_pass : (uint32_t)std::max<size_t>(1, budget / n_local);
+    // Samples per pixel traced together. The bounces of a pass are dependent rounds of launches, each with a latency floor and a
+    // tail, so a pass runs faster the larger it is (Book-2: 4.3 G rays/s at 64 spp per pass, 7.8 at 1536; the 1 M-sphere scene
+    // 5.2 at 16, 6.6 at 64): left to the library, a pass takes what the job asks for, up to seven eighths of the device memory
+    // that is free (232 bytes per path) - and half of that, and half again, while the allocation does not succeed.
+    size_t budget = (size_t)1 << 23;
+    if (!p->spp_per_pass) {
+        size_t free_bytes = 0, total_bytes = 0;
+        if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
+            const size_t held = ctx->cap_paths * RT_PATH_BYTES; // (this context's own pool is free for the purpose)
+            budget = std::max(budget, (free_bytes + held - (free_bytes + held) / 8) / RT_PATH_BYTES);
+        } else (void)hipGetLastError();
+    }
+    uint32_t S = p->spp_per_pass ? p->spp_per_pass : (uint32_t)std::max<size_t>(1, std::min<size_t>(budget / n_local, 0x7FFFFFFFu / n_local));
     S = std::min(S, spp);
+    if (!p->spp_per_pass && S < spp) S = (spp + (spp + S - 1u) / S - 1u) / ((spp + S - 1u) / S); // passes of equal size
     if ((size_t)n_local * S > 0x7FFFFFFFu) return ctx_fail(ctx, RT_ERR_INVALID, "render: pixels * spp_per_pass exceeds 2^31");
-    rc = ensure_paths(ctx, (size_t)n_local * S, p->max_depth);
+    for (;;) {
+        rc = ensure_paths(ctx, (size_t)n_local * S, p->max_depth);
+        if (rc != RT_ERR_OOM || p->spp_per_pass || S <= 1u) break;
+        S = (S + 1u) / 2u; // (someone else took the memory in between: a smaller pass)
+    }
     if (rc != RT_OK) return rc;
 
     PathBufs pb;
