@@ -1,13 +1,13 @@
 #!/bin/bash
 # Every profile the benchmark line quotes, in one GPU-box session (each counter set in a run of its own):
 #   tools/gpu_profile.sh            -> gpurun_out/prof/...; then `python tools/profile_summary.py r02` on the CPU side
-# Bench scene at the bench's pass size (1536 spp), and the 1 M-sphere scene (nodes out of cache) at 16 spp.
+# Bench scene at the bench's pass size (1536 spp), and the 1 M-sphere scene (nodes out of cache) at 64 spp.
 set -o pipefail
 export TMPDIR=/tmp
 out=gpurun_out/prof
 mkdir -p $out
 B="python3 tools/render_once.py --spp 1536 --passes 1"
-C="python3 tools/render_once.py --scene spheres_grid --n 1000000 --width 3840 --height 2160 --spp 16 --passes 1"
+C="python3 tools/render_once.py --scene spheres_grid --n 1000000 --width 3840 --height 2160 --spp 64 --passes 1"
 run() { # name, seconds, command...
   local name=$1 secs=$2; shift 2
   timeout -s KILL $secs "$@" > $out/$name.log 2>&1 || { echo "$name failed"; tail -5 $out/$name.log; exit 1; }
@@ -29,6 +29,6 @@ run c4_fetch 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_extend_tre
 run c4_write 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_extend_tree" -d $out -o c4_write --output-format csv -- $C
 run c4_tcc 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum --kernel-include-regex "k_extend_tree" -d $out -o c4_tcc --output-format csv -- $C
 run c4_sqx 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY --kernel-include-regex "k_extend_tree" -d $out -o c4_sqx --output-format csv -- $C
-run c4_visits 300 python3 tools/render_once.py --scene spheres_grid --n 1000000 --width 3840 --height 2160 --spp 16 --passes 2
+run c4_visits 300 python3 tools/render_once.py --scene spheres_grid --n 1000000 --width 3840 --height 2160 --spp 64 --passes 2
 ls $out | head -80
 echo all ok

@@ -163,9 +163,9 @@ seg = c4_line["segments"]
 tree_s = render_line(os.path.join(SRC, "c4_tcc.log"))["tree_ms"] * 1e-3
 plain = render_line(os.path.join(SRC, "c4_visits.log"))
 c4 = {
-    "scene": "spheres_grid n = 1 000 000, 3840x2160, 16 spp in one pass (64 MB of 64-byte nodes, 32 MB of sphere records)",
+    "scene": "spheres_grid n = 1 000 000, 3840x2160, 64 spp in one pass (64 MB of 64-byte nodes, 32 MB of sphere records)",
     "command": "rocprofv3 [--kernel-trace --stats | --pmc FETCH_SIZE | WRITE_SIZE | TCC_* | SQ_*] --kernel-include-regex k_extend_tree -- "
-               "python3 tools/render_once.py --scene spheres_grid --n 1000000 --width 3840 --height 2160 --spp 16 --passes 1",
+               "python3 tools/render_once.py --scene spheres_grid --n 1000000 --width 3840 --height 2160 --spp 64 --passes 1",
     "segments": seg, "launches": launches, "trace_launches": calls, "trace_avg_launch_ms": avg_ms,
     "unprofiled": plain,
     "FETCH_SIZE_KB_sum": f_tot["FETCH_SIZE"], "WRITE_SIZE_KB_sum": w_tot["WRITE_SIZE"],
