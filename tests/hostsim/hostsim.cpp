@@ -242,6 +242,28 @@ int hs_visit_stats(const void* blob, size_t nbytes, const rt_camera* cam, const 
     return RT_OK;
 }
 
+// Work of the traversal for a caller's rays: visits[0] node visits, visits[1 + RtRefType] object tests, summed over the rays.
+int hs_trace_visits(const void* blob, size_t nbytes, const rt_ray_d* rays, size_t n, const double* xi_rows, uint64_t* visits /* 12 */) {
+    DScene sc;
+    RtBlobHeader h;
+    if (!view_of(blob, nbytes, sc, h)) return RT_ERR_INVALID;
+    memset(visits, 0, sizeof(uint64_t) * 12);
+    g_visits = (uint64_t (*)[12])visits;
+    g_bounce = 0;
+    for (size_t i = 0; i < n; ++i) {
+        Ray r;
+        r.o = v3(rays[i].ox, rays[i].oy, rays[i].oz); r.d = v3(rays[i].dx, rays[i].dy, rays[i].dz); r.tm = rays[i].time;
+        VecStack st;
+        ArrayXi xi;
+        xi.row = xi_rows ? xi_rows + i * sc.n_media : nullptr;
+        HeldRay held;
+        held.r = r;
+        (void)rt_extend(sc, held, rays[i].tmin, rays[i].tmax, st, xi, xi_rows == nullptr);
+    }
+    g_visits = nullptr;
+    return RT_OK;
+}
+
 void hs_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
     Philox4 o = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
     for (int i = 0; i < 4; ++i) out[i] = o.v[i];
