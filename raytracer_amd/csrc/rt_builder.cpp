@@ -1190,9 +1190,50 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
             need += 1u;
         }
     }
-    if (!flat_refs.empty()) {
+    // A small tree that keeps the reference's order - the Cornell box: eight objects under a BvhNode whose boxes do not all
+    // bound (hittable.rs:115-143) - is not worth a stack per lane: nearly every ray enters nearly every box, each lane takes
+    // a step of its own per node and waits for the others at every leaf. Its depth-first walk is the same sequence of
+    // steps for every ray (bvh.rs:112-122: own box, left, right), so it goes onto the lock-step list as those steps
+    // (RT_REF_STEPS), behind the list's other entries as the tree was walked behind them, and the scene has no tree.
+    std::vector<uint32_t> steps;
+    if (tree_ref != RT_REF_NONE && dt_root == RT_REF_NONE && timed_refs.empty() && !getenv("RT_NO_LOCKSTEP_TREE")) {
+        const size_t kMaxSteps = 48;
+        bool ok = true;
+        std::function<void(uint32_t, uint32_t)> walk = [&](uint32_t ref, uint32_t depth) {
+            if (!ok) return;
+            if (depth > RT_STEP_MAX_DEPTH || steps.size() >= 2u * kMaxSteps) { ok = false; return; }
+            const uint32_t ty = RT_REF_TYPE(ref), idx = RT_REF_INDEX(ref);
+            if (ty == RT_REF_NODE) {
+                const RtNode& n = f.nodes[idx];
+                if (n.pad[0] == 0u) { ok = false; return; } // a tree whose boxes only cull is walked nearest first, per lane
+                if (n.c0 != RT_REF_NONE) {
+                    if (n.pad[1] != 0u) { // child 0 behind its box; without one it is entered as the node is
+                        steps.push_back(depth | RT_STEP_GATE); steps.push_back(n.pad[1]);
+                        walk(n.c0, depth + 1u);
+                    } else walk(n.c0, depth);
+                }
+                if (n.c1 != RT_REF_NONE) walk(n.c1, depth); // (never behind a box of its own in such a node)
+                return;
+            }
+            const bool leaf = ty == RT_REF_SPHERE || ty == RT_REF_MSPHERE || ty == RT_REF_RECT || ty == RT_REF_BOX || ty == RT_REF_MEDIUM ||
+                              ty == RT_REF_ILEAF || (ty == RT_REF_INST && (f.insts[idx].op & RT_INST_LEAF) != 0u);
+            if (!leaf) { ok = false; return; }
+            steps.push_back(depth); steps.push_back(ref);
+        };
+        walk(tree_ref, 1u);
+        if (ok && !steps.empty() && steps.size() <= 2u * kMaxSteps) {
+            tree_ref = RT_REF_NONE;
+            f.nodes.clear();
+            need = 0u;
+        } else steps.clear();
+    }
+    if (!flat_refs.empty() || !steps.empty()) {
         flat_ref = RT_MAKE_REF(RT_REF_LIST, f.list_entries.size());
         for (uint32_t r : flat_refs) f.list_entries.push_back(r);
+        if (!steps.empty()) {
+            f.list_entries.push_back(RT_MAKE_REF(RT_REF_STEPS, steps.size() / 2u));
+            f.list_entries.insert(f.list_entries.end(), steps.begin(), steps.end());
+        }
         f.list_entries.push_back(RT_REF_NONE);
     }
     uint32_t flat_any_ref = flat_ref;

@@ -717,6 +717,77 @@ RT_HD void rt_traverse(const DScene& sc, uint32_t root, const Ray& r, double t_m
 // ONE_MEDIUM: compiled with the short cut for a list that is one sphere-bounded medium (DScene::flat_one_medium). The
 // traversal kernel's instantiations are short of registers, each in its own way; only the one that scenes like the
 // Book-2 scene get carries it (elsewhere the same few lines cost 1 - 1.5 % of the kernel's time and won nothing).
+// One entry of a lock-step list - a primitive or medium, alone or below instances: named by its reference, RT_REF_ILEAF,
+// or below linked records, RT_REF_INST (the compiler never puts a named leaf under linked records on such a list).
+// `r` is the world ray on entry and on return.
+template <class XiFn, class RayFn>
+RT_HD void rt_flat_entry(const DScene& sc, uint32_t e, Ray& r, const RayFn& world_ray, double t_min, RtBest& best, const XiFn& xi,
+                         bool skip_media) {
+    bool moved = false;
+    if (RT_REF_TYPE(e) == RT_REF_ILEAF) {
+        r = rt_apply_chain(sc, RT_ILEAF_CHAIN(e), r);
+        e = RT_ILEAF_PRIM(e);
+        moved = true;
+    }
+#pragma unroll 1
+    while (RT_REF_TYPE(e) == RT_REF_INST) {
+        const RtInst in = sc.insts[RT_REF_INDEX(e)];
+        r = rt_apply_inst(in, r);
+        e = in.child;
+        moved = true;
+    }
+    rt_test_leaf(sc, e, r, t_min, best, xi, skip_media);
+    if (moved) r = world_ray();
+}
+
+// A small tree in the reference's order (RT_REF_STEPS), walked by all lanes together: BvhNode::hit tests its box against
+// the closest distance so far, then left, then right (bvh.rs:112-122), so the walk is the same sequence of steps for every
+// ray and only WHICH steps a ray takes part in differs - one bit per depth says whether the lane is inside. Every step's
+// operands are wave-uniform (scalar loads), no lane keeps a stack, and no lane waits for another to reach a leaf. The box
+// tests are AABB::hit on the reference's f64 bounds (aabb.rs:35-75), with 1 / d as the reference computes it.
+// `at` = index of the RT_REF_STEPS entry; returns the number of list words the steps occupy.
+template <class XiFn, class RayFn>
+RT_HD uint32_t rt_flat_steps(const DScene& sc, uint32_t at, Ray& r, const RayFn& world_ray, double t_min, RtBest& best,
+                             const XiFn& xi, bool skip_media) {
+    const uint32_t n_steps = RT_REF_INDEX(sc.list_entries[at]);
+    RtSlab k;
+    k.inv = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    k.nx = k.inv.x < 0.0; k.ny = k.inv.y < 0.0; k.nz = k.inv.z < 0.0;
+    uint32_t inside = 1u; // bit d: the lane is inside the subtree at depth d
+#pragma unroll 1
+    for (uint32_t j = 0u; j < n_steps; ++j) {
+        const uint32_t ctrl = sc.list_entries[at + 1u + 2u * j], operand = sc.list_entries[at + 2u + 2u * j];
+        const uint32_t d = ctrl & RT_STEP_DEPTH_MASK;
+        const bool here = ((inside >> (d - 1u)) & 1u) != 0u;
+        if ((ctrl & RT_STEP_GATE) != 0u) {
+            bool h = false;
+            if (here) {
+                RT_VISIT(0u);
+                bool known = true;
+#ifdef RT_BOUNDS_CHECK
+                known = RT_IN_RANGE(sc, exact_boxes, operand - 1u, ctrl);
+#endif
+                if (known) {
+                    const RtExactBox b = sc.exact_boxes[operand - 1u];
+                    double entered;
+                    h = rt_aabb_hit(b.lo, b.hi, r, k, t_min, best.t, entered);
+                }
+            }
+            inside = (inside & ~(1u << d)) | ((h ? 1u : 0u) << d);
+        } else if (here) {
+            rt_flat_entry(sc, operand, r, world_ray, t_min, best, xi, skip_media);
+        }
+    }
+    return 2u * n_steps;
+}
+
+// The world entries that are a primitive or a medium, possibly wrapped in Translate / RotateY: every lane
+// tests the same entry at the same time, so entry and parameters are wave-uniform (scalar loads, no stack).
+// ONE_MEDIUM: compiled with the short cut for a list that is one sphere-bounded medium (DScene::flat_one_medium), and
+// without the walk of a small tree (RT_REF_STEPS: a scene that has one has no other tree, and its kernels are the ones
+// without the short cut). The traversal kernel's instantiations are short of registers, each in its own way; only the one
+// that scenes like the Book-2 scene get carries the short cut (elsewhere the same few lines cost 1 - 1.5 % of the kernel's
+// time and won nothing).
 template <bool ONE_MEDIUM = false, class XiFn, class RayFn>
 RT_HD void rt_extend_flat(const DScene& sc, const RayFn& world_ray, double t_min, RtBest& best, const XiFn& xi, bool skip_media) {
     if (sc.world_flat == RT_REF_NONE) return;
@@ -731,25 +802,10 @@ RT_HD void rt_extend_flat(const DScene& sc, const RayFn& world_ray, double t_min
     Ray r = world_ray();
 #pragma unroll 1
     for (uint32_t li = RT_REF_INDEX(sc.world_flat);; ++li) {
-        uint32_t e = sc.list_entries[li];
+        const uint32_t e = sc.list_entries[li];
         if (e == RT_REF_NONE) break;
-        bool moved = false;
-        // (an entry is a primitive or medium, alone or below instances: named by its reference, RT_REF_ILEAF, or below linked
-        // records, RT_REF_INST - the compiler never puts a named leaf under linked records on this list)
-        if (RT_REF_TYPE(e) == RT_REF_ILEAF) {
-            r = rt_apply_chain(sc, RT_ILEAF_CHAIN(e), r);
-            e = RT_ILEAF_PRIM(e);
-            moved = true;
-        }
-#pragma unroll 1
-        while (RT_REF_TYPE(e) == RT_REF_INST) {
-            const RtInst in = sc.insts[RT_REF_INDEX(e)];
-            r = rt_apply_inst(in, r);
-            e = in.child;
-            moved = true;
-        }
-        rt_test_leaf(sc, e, r, t_min, best, xi, skip_media);
-        if (moved) r = world_ray();
+        if (!ONE_MEDIUM && RT_REF_TYPE(e) == RT_REF_STEPS) { li += rt_flat_steps(sc, li, r, world_ray, t_min, best, xi, skip_media); continue; }
+        rt_flat_entry(sc, e, r, world_ray, t_min, best, xi, skip_media);
     }
 }
 

@@ -506,7 +506,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
                     HeldRay held;
                     held.r = &s.r;
                     rt_extend_flat<CHAINS>(sc, held, t_min, s.best, xi_of(id, path), skip_media);
-                    s.slab = rt_slab_of<EXACT_NODES>(s.r, sc.node_extent);
+                    if (CHAINS || sc.world_tree != RT_REF_NONE) s.slab = rt_slab_of<EXACT_NODES>(s.r, sc.node_extent); // (a scene without a tree: none of the CHAINS instantiations is its kernel)
                     s.cur = sc.world_tree;
                     st.clear();
                     active = true;
@@ -1137,7 +1137,9 @@ int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t f
     const bool all_cached = n_cached == sc->hdr.nodes.count; // every node of the scene has a place in LDS
     out->kernel = table[exact_nodes][sphere_media][query][all_cached];
     // leaves named with their chain, in an instantiation that has the registers for it: their records fetched together
-    if (sc->hdr.chains.count != 0u && !exact_nodes && sphere_media) {
+    // (not for a scene without a tree: its lock-step list may hold a small tree's steps, which that instantiation's list walk
+    // leaves out)
+    if (sc->hdr.chains.count != 0u && !exact_nodes && sphere_media && sc->hdr.world_tree != RT_REF_NONE) {
         static const ExtendKernel with_chains[2][2] = {{k_extend_tree<false, true, false, false, true>, k_extend_tree<false, true, false, true, true>},
                                                        {k_extend_tree<false, true, true, false, true>, k_extend_tree<false, true, true, true, true>}};
         out->kernel = with_chains[query][all_cached];

@@ -10,7 +10,7 @@
 #include <stdint.h>
 
 #define RT_BLOB_MAGIC 0x31425452u /* "RTB1" little endian */
-#define RT_BLOB_VERSION 14u
+#define RT_BLOB_VERSION 15u
 
 // ---- tagged references -------------------------------------------------------------------------
 enum RtRefType : uint32_t {
@@ -28,6 +28,12 @@ enum RtRefType : uint32_t {
                          // ref itself: aux = the primitive's type - RT_REF_SPHERE, index = chain[25:20] | primitive[19:0]
                          // (RtChain record, record of the primitive's own table). A traversal needs no dependent reads to
                          // test it. The compiler emits it wherever chain and primitive numbers fit, RT_REF_INST otherwise.
+    ,
+    RT_REF_STEPS = 11    // on a lock-step list only: index = n, and the 2 n words behind it are a small reference-order tree
+                         // (bvh.rs:112-122) laid out as the steps of its depth-first walk, (control, operand) each: control =
+                         // depth | RT_STEP_GATE for a box test (operand = 1 + index of its f64 bounds in exact_boxes; lanes that
+                         // are inside at depth - 1 and pass are inside at depth), control = depth for an object (operand = its
+                         // reference; tested by the lanes inside at depth - 1). The walk starts with every lane inside at depth 0.
 };
 // layout: type[31:28] | aux[27:26] (zero but in RT_REF_ILEAF) | index[25:0]
 #define RT_REF_SHIFT 28u
@@ -39,6 +45,9 @@ enum RtRefType : uint32_t {
 #define RT_REF_AUX(ref) (((uint32_t)(ref) >> RT_REF_AUX_SHIFT) & 3u)
 #define RT_REF_STRIP_AUX(ref) ((uint32_t)(ref) & ~(3u << RT_REF_AUX_SHIFT))
 
+#define RT_STEP_GATE 0x100u
+#define RT_STEP_DEPTH_MASK 63u
+#define RT_STEP_MAX_DEPTH 31u
 #define RT_ILEAF_CHAIN_SHIFT 20u
 #define RT_ILEAF_PRIM_MASK 0xFFFFFu
 #define RT_ILEAF_MAX_CHAINS 64u

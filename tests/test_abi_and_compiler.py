@@ -171,7 +171,33 @@ def test_blob_layout_of_the_book2_final_scene():
     assert chain["op"][1]["a"] == insts[1]["a"] == np.sin(np.radians(15.0)) or abs(chain["op"][1]["a"] - np.sin(np.radians(15.0))) < 1e-15
 
 
-def test_cornell_replays_the_reference_order():
+def test_a_small_reference_order_tree_becomes_lock_step_steps():
+    """The Cornell box is eight objects under a BvhNode whose boxes do not all bound: its depth-first walk (bvh.rs:112-122)
+    goes onto the lock-step list as steps - a box test per BvhNode, in front of the root's too, and one in front of the
+    world's entry - and the scene has no tree and no node."""
+    b, info, blob, _ = util.build_scene("cornell_box")
+    h = header(blob)
+    s = h["sections"]
+    assert s["nodes"][1] == 0 and h["world_tree"] == 0 and (h["world_flat"] >> 28) == 8 and h["stack_need"] == 1
+    entries = np.frombuffer(blob, dtype="<u4", count=s["list_entries"][1], offset=s["list_entries"][0])
+    at = h["world_flat"] & 0x03FFFFFF
+    assert entries[at] >> 28 == 11
+    n = int(entries[at] & 0x03FFFFFF)
+    ctrl, operand = entries[at + 1:at + 1 + 2 * n:2], entries[at + 2:at + 2 + 2 * n:2]
+    assert entries[at + 1 + 2 * n] == 0                       # the list ends behind the steps
+    gates = (ctrl & 0x100) != 0
+    depth = ctrl & 63
+    assert gates.sum() == 7 + 1 and (~gates).sum() == 8       # 7 BvhNodes (bvh.rs:33-50) + the world's entry; 8 objects
+    assert sorted((operand[~gates] >> 28).tolist()) == [4] * 6 + [10] * 2   # six rects, two boxes named with their chains
+    assert sorted(operand[gates].tolist()) == list(range(1, 9)) and s["exact_boxes"][1] == 8
+    # depth-first: a step is at most one level below the step before it, the walk starts at depth 1, and what follows a
+    # box test one level down is inside it
+    assert depth[0] == 1 and gates[0] and np.all(np.diff(depth.astype(int)) <= 1) and depth.max() <= 31
+    assert all(depth[i + 1] == depth[i] + 1 for i in range(n - 1) if gates[i])
+
+
+def test_cornell_replays_the_reference_order(monkeypatch):
+    monkeypatch.setenv("RT_NO_LOCKSTEP_TREE", "1")            # the form a larger tree of that kind takes
     b, info, blob, _ = util.build_scene("cornell_box")
     h = header(blob)
     # 8 objects -> 7 BvhNodes (bvh.rs:33-50); each node one record, + one record in front of the root and of every
