@@ -214,11 +214,14 @@ int rt_trace_first_hit(rt_context*, const rt_scene*, const rt_ray_d* rays, size_
                        rt_hit* out);
 
 /* The same query answered by the kernel the renderer spends its time in (k_extend_tree: persistent waves, node cache
- * in LDS, leaf rounds, queue dealt in pieces) instead of the one-lane-one-ray kernel of rt_trace_first_hit: same arguments,
- * same results bit for bit except the winner of an exact tie. Exists so that the parity gate of hittable_list.rs:40-53 /
- * bvh.rs:112-122 can be put on the kernel that is benchmarked; also the faster of the two for large batches.
+ * in LDS, leaf rounds, queue dealt in pieces; for a scene whose world is all on the lock-step list - a few objects, or a
+ * small reference-order tree as steps - k_extend_list: one ray per lane, the list front to back) instead of the
+ * one-lane-one-ray kernel of rt_trace_first_hit: same arguments, same results bit for bit except the winner of an exact
+ * tie. Exists so that the parity gate of hittable_list.rs:40-53 / bvh.rs:112-122 can be put on the kernel that is
+ * benchmarked; also the faster of the two for large batches.
  * variant: bit 0 = use the instantiation with exact f64 box tests (aabb.rs:35-75) even if no node of the scene needs them,
- * bit 1 = the one with the general ConstantMedium boundary code even if every medium is bounded by a sphere. */
+ * bit 1 = the one with the general ConstantMedium boundary code even if every medium is bounded by a sphere,
+ * bit 2 = k_extend_tree even for a scene without a tree. */
 int rt_trace_first_hit_wavefront(rt_context*, const rt_scene*, const rt_ray_d* rays, size_t n, const double* medium_xi,
                                  rt_hit* out, uint32_t variant);
 

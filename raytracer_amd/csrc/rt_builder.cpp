@@ -894,6 +894,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         }
     };
     struct Item { int handle; bool bounded; AABB box; bool flatable; bool timed; int wrapped; };
+    const size_t kTinyWorld = getenv("RT_TINY_WORLD") ? (size_t)atoi(getenv("RT_TINY_WORLD")) : 10u;
     // A member of a BvhNode or list that stands under instances, taken out to be an entry of its own under the same
     // instances: `chain` = the Translate/RotateY objects from the outside in, `sub` = the member.
     struct Wrapped { std::vector<int> chain; int sub; };
@@ -1002,6 +1003,25 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
             items.push_back(it);
         }
         if (items.empty()) return out;
+        // A world of a few objects needs no tree: every ray tests every object, all lanes in step, in the world's own order
+        // (hittable_list.rs:45-51) - cheaper than a stack per lane and a wait at every leaf, for a handful of tests.
+        if (lock_step && items.size() <= kTinyWorld && !getenv("RT_NO_LOCKSTEP_TREE")) {
+            bool plain = true;
+            for (const Item& it : items) plain = plain && it.flatable && !it.timed && it.wrapped < 0 && objs[it.handle].kind != OBJ_MSPHERE && !has_moving(it.handle);
+            if (plain) {
+                std::vector<uint32_t> refs;
+                for (const Item& it : items) {
+                    uint32_t n = 0;
+                    const uint32_t r = emit(f, it.handle, RT_NO_PARENT, 0, n);
+                    if (r == RT_REF_NONE) { run_rc = error.empty() ? fail(RT_ERR_UNSUPPORTED, "empty scene") : RT_ERR_UNSUPPORTED; return out; }
+                    plain = plain && !(RT_REF_TYPE(r) == RT_REF_INST && (f.insts[RT_REF_INDEX(r)].op & RT_INST_LEAF) == 0u);
+                    refs.push_back(r);
+                }
+                if (plain) { flat_refs.insert(flat_refs.end(), refs.begin(), refs.end()); return out; }
+                run_rc = fail(RT_ERR_UNSUPPORTED, "an object of a small world cannot be tested in lock step");
+                return out;
+            }
+        }
         // huge = at least as large as everything smaller than it put together: peel such items off, largest first
         std::vector<char> in_tree(items.size(), 0);
         {

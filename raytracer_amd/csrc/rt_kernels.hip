@@ -578,6 +578,141 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
 #endif
 }
 
+// The closest hits of a scene WITHOUT a tree: everything the world holds is on its lock-step list (a handful of objects, or a
+// small reference-order tree laid out as steps). Every ray then runs the same sequence of tests, so there is nothing to
+// schedule - no stacks, no node cache, no refill thresholds: one ray per lane, the list from front to back, all lanes of
+// a wave in step. Same arguments as k_extend_tree's so that the two are launched alike (`steps_at`, `n_steps`: where the
+// list holds a tree's steps, 0 steps if it holds none).
+//
+// A tree's steps are wave-uniform, and read through the scalar cache each step costs a chain of dependent loads (its two
+// words, then the record they name) that nothing overlaps. So lane j of every wave fetches step j once, words and record
+// (a box test's f64 bounds; a rect's, box's or sphere's own record), before the first ray, and the walk takes each step's
+// operands out of lane j's registers (v_readlane: exec does not matter to it, a lane whose rays have run out still serves).
+struct StepOperands { uint32_t ctrl, operand; double rec[6]; };
+__device__ __forceinline__ double rt_lane_value(double v, uint32_t lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), (int)lane), __builtin_amdgcn_readlane(__double2loint(v), (int)lane));
+}
+template <class XiFn>
+__device__ inline void rt_steps_from_lanes(const DScene& sc, const StepOperands& mine, uint32_t n_steps, Ray& r, const HeldRay& world_ray,
+                                           double t_min, RtBest& best, const XiFn& xi, bool skip_media) {
+    RtSlab k;
+    k.inv = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    k.nx = k.inv.x < 0.0; k.ny = k.inv.y < 0.0; k.nz = k.inv.z < 0.0;
+    uint32_t inside = 1u;
+#pragma unroll 1
+    for (uint32_t j = 0u; j < n_steps; ++j) {
+        const uint32_t ctrl = (uint32_t)__builtin_amdgcn_readlane((int)mine.ctrl, (int)j), operand = (uint32_t)__builtin_amdgcn_readlane((int)mine.operand, (int)j);
+        double rec[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) rec[c] = rt_lane_value(mine.rec[c], j);
+        const uint32_t d = ctrl & RT_STEP_DEPTH_MASK;
+        const bool here = ((inside >> (d - 1u)) & 1u) != 0u;
+        if ((ctrl & RT_STEP_GATE) != 0u) {
+            bool h = false;
+            if (here) {
+                const double lo[3] = {rec[0], rec[1], rec[2]}, hi[3] = {rec[3], rec[4], rec[5]};
+                double entered;
+                h = rt_aabb_hit(lo, hi, r, k, t_min, best.t, entered);
+            }
+            inside = (inside & ~(1u << d)) | ((h ? 1u : 0u) << d);
+            continue;
+        }
+        const uint32_t leaf = RT_REF_TYPE(operand) == RT_REF_ILEAF ? RT_ILEAF_PRIM(operand) : operand;
+        const uint32_t ty = RT_REF_TYPE(leaf);
+        if (ty != RT_REF_SPHERE && ty != RT_REF_RECT && ty != RT_REF_BOX) { // no record in the lanes: the list's own way
+            if (here) rt_flat_entry(sc, operand, r, world_ray, t_min, best, xi, skip_media);
+            continue;
+        }
+        if (here) {
+            const bool moved = RT_REF_TYPE(operand) == RT_REF_ILEAF;
+            if (moved) r = rt_apply_chain(sc, RT_ILEAF_CHAIN(operand), r);
+            double t;
+            if (ty == RT_REF_SPHERE) {
+                if (rt_sphere_t(v3(rec[0], rec[1], rec[2]), rec[3], r, t_min, best.t, t)) { best.t = t; best.ref = leaf; best.aux = 0u; }
+            } else if (ty == RT_REF_RECT) {
+                const uint32_t axis = (uint32_t)__double2loint(rec[5]);
+                if (rt_rect_t(axis, rec[0], rec[1], rec[2], rec[3], rec[4], r, t_min, best.t, t)) { best.t = t; best.ref = leaf; best.aux = 0u; }
+            } else {
+                RtBox b;
+                b.p0[0] = rec[0]; b.p0[1] = rec[1]; b.p0[2] = rec[2]; b.p1[0] = rec[3]; b.p1[1] = rec[4]; b.p1[2] = rec[5];
+                uint32_t face = 0u;
+                if (rt_box_t(b, r, t_min, best.t, t, face)) { best.t = t; best.ref = leaf; best.aux = face; }
+            }
+            if (moved) r = world_ray();
+        }
+    }
+}
+template <bool SPHERE_MEDIA, bool QUERY>
+__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_extend_list(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it, uint32_t steps_at,
+                                                          uint32_t n_steps, uint32_t, uint32_t, uint32_t, QueryBatch qb) {
+    const PathRay* rays = pb.ray[it & 1u];
+    LiveSet alive_paths;
+    alive_paths.front = 0u; alive_paths.back = 0u; alive_paths.cap = 0u;
+    if (QUERY) alive_paths.front = qb.n; else alive_paths = live_set(qs.counters + it * RT_COUNTER_STRIDE, qs.bucket_cap);
+    const uint32_t n = alive_paths.n();
+    typedef typename std::conditional<QUERY, ArrayXiOf<SPHERE_MEDIA>, PhiloxXi<SPHERE_MEDIA>>::type Xi;
+    const bool skip_media = QUERY && qb.xi_rows == nullptr;
+    StepOperands mine;
+    mine.ctrl = 0u; mine.operand = 0u;
+    for (int c = 0; c < 6; ++c) mine.rec[c] = 0.0;
+    {
+        const uint32_t j = __lane_id();
+        if (j < n_steps) {
+            mine.ctrl = sc.list_entries[steps_at + 1u + 2u * j]; mine.operand = sc.list_entries[steps_at + 2u + 2u * j];
+            const uint32_t leaf = RT_REF_TYPE(mine.operand) == RT_REF_ILEAF ? RT_ILEAF_PRIM(mine.operand) : mine.operand;
+            const double* src = nullptr;
+            uint32_t n_doubles = 6u;
+            if ((mine.ctrl & RT_STEP_GATE) != 0u) src = (const double*)(sc.exact_boxes + (mine.operand - 1u));
+            else if (RT_REF_TYPE(leaf) == RT_REF_SPHERE) { src = (const double*)(sc.spheres + RT_REF_INDEX(leaf)); n_doubles = 4u; }
+            else if (RT_REF_TYPE(leaf) == RT_REF_RECT) src = (const double*)(sc.rects + RT_REF_INDEX(leaf)); // (the sixth: axis and padding)
+            else if (RT_REF_TYPE(leaf) == RT_REF_BOX) src = (const double*)(sc.boxes + RT_REF_INDEX(leaf));
+            if (src != nullptr)
+                for (uint32_t c = 0u; c < 6u; ++c) if (c < n_doubles) mine.rec[c] = src[c];
+        }
+    }
+    for (uint32_t base = blockIdx.x * RT_BLOCK + (threadIdx.x & ~63u); base < n; base += gridDim.x * RT_BLOCK) { // (a wave stays together)
+        const uint32_t i = base + __lane_id();
+        const bool has_ray = i < n;
+        const uint32_t path = alive_paths.record(has_ray ? i : 0u);
+        double t_min = 0.001; // main.rs:56; a query ray brings its own
+        RtBest best;
+        best.t = RT_INF; best.ref = RT_REF_NONE; best.aux = 0u;
+        PathId id;
+        id.slot = 0u; id.pixel = 0u;
+        Ray r;
+        Xi xi;
+        if constexpr (QUERY) {
+            QueryRay q;
+            q.q = qb.rays + path;
+            r = q();
+            t_min = q.q->tmin; best.t = q.q->tmax;
+            xi.row = qb.xi_rows ? qb.xi_rows + (size_t)path * sc.n_media : nullptr;
+        } else {
+            r = load_ray(rays + path, id);
+            xi.pi = &pi; xi.id = id; xi.bounce = it;
+        }
+        HeldRay held;
+        held.r = &r;
+        if (has_ray) {
+            if (n_steps == 0u) {
+                rt_extend_flat(sc, held, t_min, best, xi, skip_media);
+            } else { // the list's entries in front of the steps, the steps, the entries behind them
+                Ray moving = r;
+                uint32_t li = RT_REF_INDEX(sc.world_flat);
+#pragma unroll 1
+                for (; li < steps_at; ++li) rt_flat_entry(sc, sc.list_entries[li], moving, held, t_min, best, xi, skip_media);
+                rt_steps_from_lanes(sc, mine, n_steps, moving, held, t_min, best, xi, skip_media);
+#pragma unroll 1
+                for (li = steps_at + 1u + 2u * n_steps; sc.list_entries[li] != RT_REF_NONE; ++li)
+                    rt_flat_entry(sc, sc.list_entries[li], moving, held, t_min, best, xi, skip_media);
+            }
+            RtHitLite h;
+            h.t = best.t; h.ref = best.ref; h.aux = best.aux;
+            (QUERY ? qb.hit : pb.hit)[path] = h;
+        }
+    }
+}
+
 // emitted + scatter (main.rs:60-70) for every path of iteration `it` that hit a material of type MAT.
 template <uint32_t BUCKET>
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it) {
@@ -907,6 +1042,7 @@ struct rt_scene {
     uint32_t bucket_mask = 0;              // shading buckets some material of the scene falls into
     bool sphere_media = true;              // every medium is bounded by a plain sphere (no instance, no other primitive)
     bool tree_built = false;               // rt_scene_build_tree_device has replaced the stand-in tree
+    uint32_t steps_at = 0u, n_steps = 0u;  // a small tree's steps on the lock-step list: index of their RT_REF_STEPS entry, their number (0: none)
     // [0]: hdr.world_flat, [1]: hdr.world_flat_any_time - the list's one medium and its sphere when that is all the list holds
     struct OneMedium { uint32_t ref = 0u; RtMedium medium; RtSphere sphere; } one_medium[2];
     void choose_flat(uint32_t which) { // the list the view's world_flat names, as DScene::flat_one_medium wants it
@@ -1109,9 +1245,17 @@ struct ExtendLaunch {
     ExtendKernel kernel;
     size_t lds;
     uint32_t stack_cap, n_cached, n_exact_lds, refill_min, leaf_pct;
+    bool list_only; // the scene has no tree: k_extend_list, launched over the rays instead of one persistent workgroup per CU
+    uint32_t block;
+    uint32_t stack_cap_arg = 0u, refill_arg = 0u; // the kernel's fifth and sixth arguments: stack_cap and refill_min for k_extend_tree
+    uint32_t grid(const rt_context* ctx, size_t rays) const {
+        const size_t want = (rays + block - 1) / block;
+        return (uint32_t)std::max<size_t>(1, std::min<size_t>(want, (size_t)ctx->n_cu * (list_only ? 32u : 1u)));
+    }
 };
 // `force`: bit 0 = the instantiation with exact f64 box tests even if the scene has no node that needs them, bit 1 = the
-// one with the general medium-boundary code even if every medium is bounded by a sphere (both are valid for any scene).
+// one with the general medium-boundary code even if every medium is bounded by a sphere (both are valid for any scene),
+// bit 2 = the tree kernel even for a scene without a tree.
 int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t force, ExtendLaunch* out) {
     const uint32_t stack_cap = sc->hdr.stack_need;
     // Persistent waves, one workgroup per CU: its LDS holds the traversal stacks and, in what is left, the first
@@ -1144,11 +1288,20 @@ int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t f
                                                        {k_extend_tree<false, true, true, false, true>, k_extend_tree<false, true, true, true, true>}};
         out->kernel = with_chains[query][all_cached];
     }
+    out->list_only = sc->hdr.world_tree == RT_REF_NONE && !(force & 4u);
+    if (out->list_only) { // nothing to walk per lane
+        static const ExtendKernel lists[2][2] = {{k_extend_list<false, false>, k_extend_list<false, true>}, {k_extend_list<true, false>, k_extend_list<true, true>}};
+        out->kernel = lists[sphere_media][query];
+        lds = 0;
+        out->stack_cap_arg = sc->steps_at; out->refill_arg = sc->n_steps; // (what k_extend_list takes in those two places)
+    }
     if (lds > 65536)
         RT_HIP(hipFuncSetAttribute((const void*)out->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size of k_extend_tree");
     if (getenv("RT_DEBUG"))
         fprintf(stderr, "rt: lds_per_block %zu, stack_need %u, nodes %llu, cached %u, lds %zu\n", ctx->lds_per_block, stack_cap,
                 (unsigned long long)sc->hdr.nodes.count, n_cached, lds);
+    out->block = out->list_only ? (uint32_t)RT_BLOCK : (uint32_t)RT_TREE_BLOCK;
+    if (!out->list_only) { out->stack_cap_arg = stack_cap; out->refill_arg = out->refill_min; }
     out->lds = lds; out->stack_cap = stack_cap; out->n_cached = n_cached; out->n_exact_lds = n_exact_lds;
     return RT_OK;
 }
@@ -1294,6 +1447,17 @@ static int upload_common(rt_context* ctx, const void* src, size_t nbytes, bool s
             s->one_medium[w].medium = m;
             s->one_medium[w].sphere = sp;
         }
+        // a small tree's steps on the lock-step list (the compiler puts them on a list that serves rays of any time)
+        s->steps_at = 0u; s->n_steps = 0u;
+        if (s->hdr.world_flat != RT_REF_NONE && RT_REF_TYPE(s->hdr.world_flat) == RT_REF_LIST && s->hdr.world_flat == s->hdr.world_flat_any_time) {
+            for (size_t li = RT_REF_INDEX(s->hdr.world_flat); li < entries.size() && entries[li] != RT_REF_NONE; ++li) {
+                if (RT_REF_TYPE(entries[li]) != RT_REF_STEPS) continue;
+                const uint32_t n_steps = RT_REF_INDEX(entries[li]);
+                if (n_steps > 64u || li + 1u + 2u * (size_t)n_steps >= entries.size()) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_INVALID, "blob: a tree's steps run past the list"); }
+                s->steps_at = (uint32_t)li; s->n_steps = n_steps;
+                break;
+            }
+        }
         s->choose_flat(1u); // (make_view names the any-time list)
     }
     *out = s;
@@ -1388,7 +1552,7 @@ int rt_trace_first_hit(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays
 int rt_trace_first_hit_wavefront(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays, size_t n, const double* medium_xi,
                                  rt_hit* out, uint32_t variant) try {
     if (!ctx) return RT_ERR_INVALID;
-    if (!sc || (!rays && n) || (!out && n) || n > 0x7FFFFFFFu || variant > 3u) return ctx_fail(ctx, RT_ERR_INVALID, "trace_first_hit_wavefront: bad argument");
+    if (!sc || (!rays && n) || (!out && n) || n > 0x7FFFFFFFu || variant > 7u) return ctx_fail(ctx, RT_ERR_INVALID, "trace_first_hit_wavefront: bad argument");
     if (n == 0) return RT_OK;
     for (size_t i = 0; i < n; ++i)
         if (rays[i].time < sc->hdr.valid0 || rays[i].time > sc->hdr.valid1)
@@ -1418,9 +1582,8 @@ int rt_trace_first_hit_wavefront(rt_context* ctx, const rt_scene* sc, const rt_r
         QueueSet qs;
         memset(&qs, 0, sizeof qs);
         qs.error_flag = ctx->error_flag;
-        const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min<size_t>((n + RT_TREE_BLOCK - 1) / RT_TREE_BLOCK, (size_t)ctx->n_cu));
-        hipLaunchKernelGGL(xl.kernel, dim3(grid), dim3(RT_TREE_BLOCK), xl.lds, ctx->stream, sc->view, pi, pb, qs, 0u, xl.stack_cap,
-                           xl.refill_min, xl.leaf_pct, xl.n_cached, xl.n_exact_lds, qb);
+        hipLaunchKernelGGL(xl.kernel, dim3(xl.grid(ctx, n)), dim3(xl.block), xl.lds, ctx->stream, sc->view, pi, pb, qs, 0u, xl.stack_cap_arg,
+                           xl.refill_arg, xl.leaf_pct, xl.n_cached, xl.n_exact_lds, qb);
         hipLaunchKernelGGL(k_query_finish, dim3(grid_for(ctx, n, 8)), dim3(RT_BLOCK), 0, ctx->stream, sc->view, qb, d_out);
         e = hipGetLastError();
     }
@@ -1559,10 +1722,9 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
     ExtendLaunch xl;
     rc = extend_launch_of(ctx, sc, false, 0u, &xl);
     if (rc != RT_OK) return rc;
-    const uint32_t stack_cap = xl.stack_cap, refill_min = xl.refill_min, leaf_pct = xl.leaf_pct, n_cached = xl.n_cached, n_exact_lds = xl.n_exact_lds;
+    const uint32_t leaf_pct = xl.leaf_pct, n_cached = xl.n_cached, n_exact_lds = xl.n_exact_lds;
     const size_t lds = xl.lds;
     const ExtendKernel k_extend = xl.kernel;
-    const uint32_t extend_blocks_per_cu = 1u;
     QueryBatch no_query;
     no_query.rays = nullptr; no_query.xi_rows = nullptr; no_query.hit = nullptr; no_query.n = 0u;
     const size_t n_counters = (size_t)(p->max_depth + 2) * RT_COUNTER_STRIDE;
@@ -1587,12 +1749,12 @@ int rt_render_accumulate(rt_context* ctx, const rt_scene* sc, const rt_camera* c
         size_t a = tm.begin();
         hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, paths, 128)), dim3(RT_BLOCK), 0, ctx->stream, cd, pi, pb);
         tm.end(a, 0);
-        const uint32_t g_ext = (uint32_t)std::max<size_t>(1, std::min<size_t>((paths + RT_TREE_BLOCK - 1) / RT_TREE_BLOCK, (size_t)ctx->n_cu * extend_blocks_per_cu));
+        const uint32_t g_ext = xl.grid(ctx, paths);
         const uint32_t g_sh = grid_for(ctx, paths, 128); // (many more workgroups than fit at once: 8 per CU, each looping longer, cost k_shade_main 7 %)
         for (uint32_t it = 0; it < p->max_depth; ++it) {
             a = tm.begin();
-            hipLaunchKernelGGL(k_extend, dim3(g_ext), dim3(RT_TREE_BLOCK), lds, ctx->stream, local.view, pi, pb, qs, it, stack_cap,
-                               refill_min, leaf_pct, n_cached, n_exact_lds, no_query);
+            hipLaunchKernelGGL(k_extend, dim3(g_ext), dim3(xl.block), lds, ctx->stream, local.view, pi, pb, qs, it, xl.stack_cap_arg,
+                               xl.refill_arg, leaf_pct, n_cached, n_exact_lds, no_query);
             tm.end(a, 1);
             a = tm.begin();
             hipLaunchKernelGGL(k_shade_main, dim3(g_sh), dim3(RT_BLOCK), 0, ctx->stream, local.view, pi, pb, qs, it);
