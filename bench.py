@@ -15,6 +15,7 @@ import argparse
 import hashlib
 import json
 import os
+import struct
 import sys
 import time
 
@@ -270,6 +271,9 @@ def main():
                     j.get("max_depth", 50) == info.max_depth and args.compat == 0)
             return j if same else None
         traffic, counters_from, valu = None, {}, None
+        # the closest-hit kernel of this scene: a scene whose world is all on the lock-step list (RtBlobHeader::world_tree,
+        # the u32 at byte 24, is 0) runs k_extend_list, every other one k_extend_tree
+        extend_kernel = "k_extend_list" if struct.unpack_from("<I", bytes(blob[:32]), 24)[0] == 0 else "k_extend_tree"
         def first_of(*names):  # per-scene files (tools/gpu_profile_config.sh), then the bench scene's (tools/gpu_profile.sh)
             for nm in names:
                 j = counters_of(os.path.join(ROOT, "profiles", nm))
@@ -284,7 +288,7 @@ def main():
                                         "correction": "FETCH_SIZE x 2 (gfx950, 16-byte-per-lane streaming reads) + WRITE_SIZE"}
         sq_name, sqj = first_of(args.scene + "_sq_counters.json", "sq_counters.json")  # rocprofv3 --pmc SQ_* passes
         if sqj:
-            sq = sqj.get("k_extend_tree", {})
+            sq = sqj.get(extend_kernel) or sqj.get("k_extend_tree", {})
             if sq.get("valu_busy") is not None and sq.get("lane_use") is not None:
                 # the bound this kernel runs against: the share of the vector unit's issue slots that do useful lanes
                 valu = {"busy": sq["valu_busy"], "lane_use": sq["lane_use"], "frac": sq["valu_busy"] * sq["lane_use"],
@@ -311,7 +315,7 @@ def main():
                 # peak (measured here). The kernel is not bound by HBM: the scene sits in L2 / LDS, and what limits it is
                 # the vector unit under divergence - valu_busy x valu_lane_use, from the SQ counters (counters_from) - and the
                 # chain of dependent steps a wave runs per node and leaf, with four waves per SIMD to overlap them.
-                "kernel": "k_extend_tree", "bound": "valu", "valu": valu,
+                "kernel": extend_kernel, "bound": "valu", "valu": valu,
                 # the HBM side, as the bench contract states it (achieved / peak / frac are HBM figures, not the bound's):
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "frac_of": "hbm", "traffic": traffic,
                 "bytes_per_segment": EXTEND_BYTES_PER_SEGMENT, "segments_per_launch": seg_per_launch,

@@ -1005,7 +1005,8 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
         if (items.empty()) return out;
         // A world of a few objects needs no tree: every ray tests every object, all lanes in step, in the world's own order
         // (hittable_list.rs:45-51) - cheaper than a stack per lane and a wait at every leaf, for a handful of tests.
-        if (lock_step && items.size() <= kTinyWorld && !getenv("RT_NO_LOCKSTEP_TREE")) {
+        // (not when the caller asked for a tree to build on the device: rt_scene_build_tree_device must find one)
+        if (lock_step && items.size() <= kTinyWorld && !(flags & RT_BLOB_FLAG_DEVICE_TREE) && !getenv("RT_NO_LOCKSTEP_TREE")) {
             bool plain = true;
             for (const Item& it : items) plain = plain && it.flatable && !it.timed && it.wrapped < 0 && objs[it.handle].kind != OBJ_MSPHERE && !has_moving(it.handle);
             if (plain) {

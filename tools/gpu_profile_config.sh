@@ -13,9 +13,9 @@ out=gpurun_out/cfg_$name
 mkdir -p $out/out
 R="python3 tools/render_once.py --spp $spp --passes 1 $*"
 run() { local n=$1 secs=$2; shift 2; timeout -s KILL $secs "$@" > $out/$n.log 2>&1 || { echo "$n failed"; tail -5 $out/$n.log; exit 1; }; echo "$n ok"; }
-run fetch 240 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_extend_tree" -d $out -o fetch --output-format csv -- $R
-run write 240 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_extend_tree" -d $out -o write --output-format csv -- $R
-run sqx 240 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY --kernel-include-regex "k_extend_tree" -d $out -o sqx --output-format csv -- $R
+run fetch 240 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_extend_" -d $out -o fetch --output-format csv -- $R
+run write 240 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_extend_" -d $out -o write --output-format csv -- $R
+run sqx 240 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY --kernel-include-regex "k_extend_" -d $out -o sqx --output-format csv -- $R
 python3 tools/profile_config_summary.py $name $spp $out "$@" || exit 1
 # the counters just written are what bench.py will quote: copy them where it looks
 cp $out/out/${name}_extend_hbm_traffic.json $out/out/${name}_sq_counters.json profiles/
@@ -26,5 +26,5 @@ python3 - <<PY
 import json
 j = json.loads(open("$out/out/bench.json").read().strip().splitlines()[-1])
 r = j["roofline"]
-print("$name: %.3f G rays/s, %.1f ms/step; k_extend_tree %.3f ms/launch, hbm frac %.3f, valu %s, traffic %s" % (j["value"] / 1e9, j["ms_per_step"], r["avg_launch_ms"], r["frac"], r["valu"], r["traffic"]))
+print("$name: %.3f G rays/s, %.1f ms/step; %s %.3f ms/launch, hbm frac %.3f, valu %s, traffic %s" % (j["value"] / 1e9, j["ms_per_step"], r["kernel"], r["avg_launch_ms"], r["frac"], r["valu"], r["traffic"]))
 PY

@@ -1,4 +1,4 @@
-"""Counters of k_extend_tree for one configuration -> the two JSON files bench.py quotes for that scene and image size.
+"""Counters of the closest-hit kernel (k_extend_tree; k_extend_list for a scene without a tree) for one configuration -> the two JSON files bench.py quotes for that scene and image size.
     python tools/profile_config_summary.py <name> <spp per pass> <directory of the rocprofv3 runs> [scene arguments as given to render_once.py]
 FETCH_SIZE / WRITE_SIZE are KB; FETCH_SIZE x 2 on gfx950 for the 16-byte-per-lane streaming reads of the ray records;
 SQ_BUSY_CYCLES is summed over 32 shader engines; a VALU instruction occupies its SIMD for 4 cycles; 1024 SIMDs."""
@@ -24,10 +24,15 @@ def find(fname):
     raise FileNotFoundError(fname)
 
 
+KERNELS = set()  # k_extend_tree, or k_extend_list for a scene without a tree
+
+
 def per_dispatch(path):
     by = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
-        if r["Kernel_Name"].replace("void ", "").startswith("k_extend_tree"):
+        kn = r["Kernel_Name"].replace("void ", "")
+        if kn.startswith("k_extend_"):
+            KERNELS.add(kn.split("<")[0].split("(")[0])
             by.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
     return [by[k] for k in sorted(by)]
 
@@ -62,8 +67,9 @@ common = {"scene": scene, "width": width, "height": height, "max_depth": info.ma
 f_rows, w_rows = per_dispatch(find("fetch_counter_collection.csv")), per_dispatch(find("write_counter_collection.csv"))
 fetch, write = total(f_rows)["FETCH_SIZE"] * 1024.0, total(w_rows)["WRITE_SIZE"] * 1024.0
 launches, seg = len(f_rows), line["segments"]
-traffic = dict(common, kernel="k_extend_tree", launches=launches, segments_per_launch=seg / launches,
-               command="rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-include-regex k_extend_tree -- python3 tools/render_once.py --spp %d --passes 1 %s (separate runs)" % (spp, " ".join(args)),
+kernel = sorted(KERNELS)[0] if len(KERNELS) == 1 else "k_extend_tree"
+traffic = dict(common, kernel=kernel, launches=launches, segments_per_launch=seg / launches,
+               command="rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-include-regex k_extend_ -- python3 tools/render_once.py --spp %d --passes 1 %s (separate runs)" % (spp, " ".join(args)),
                hbm_bytes_per_launch=(fetch + write) / launches, hbm_bytes_per_launch_corrected=(2.0 * fetch + write) / launches,
                fetched_bytes_per_segment_corrected=2.0 * fetch / seg, fetched_bytes_per_segment_as_reported=fetch / seg,
                written_bytes_per_segment=write / seg, algorithmic_bytes_per_segment={"read": 56, "written": 16},
@@ -84,12 +90,13 @@ def one(d):
 
 
 sq = dict(common, command="rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY "
-                          "SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY --kernel-include-regex k_extend_tree -- python3 tools/render_once.py --spp %d --passes 1 %s" % (spp, " ".join(args)))
-sq["k_extend_tree"] = dict(one(total(sq_rows)), launches=len(sq_rows), by_bounce=[dict(one(sq_rows[i]), bounce=i) for i in (0, 1, 2, 5, 10, 20, 40) if i < len(sq_rows)])
+                          "SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY --kernel-include-regex k_extend_ -- python3 tools/render_once.py --spp %d --passes 1 %s" % (spp, " ".join(args)))
+sq["kernel"] = kernel
+sq[kernel] = dict(one(total(sq_rows)), launches=len(sq_rows), by_bounce=[dict(one(sq_rows[i]), bounce=i) for i in (0, 1, 2, 5, 10, 20, 40) if i < len(sq_rows)])
 os.makedirs(os.path.join(src, "out"), exist_ok=True)
 json.dump(traffic, open(os.path.join(src, "out", name + "_extend_hbm_traffic.json"), "w"), indent=1)
 json.dump(sq, open(os.path.join(src, "out", name + "_sq_counters.json"), "w"), indent=1)
-k = sq["k_extend_tree"]
-print("%s %dx%d @ %d spp: k_extend_tree VALU busy %.3f, lane use %.3f, waiting for memory %.3f; HBM %.1f B fetched (x2) + %.1f B written per segment" %
+k = sq[kernel]
+print("%s %dx%d @ %d spp: " + kernel + " VALU busy %.3f, lane use %.3f, waiting for memory %.3f; HBM %.1f B fetched (x2) + %.1f B written per segment" %
       (scene, width, height, spp, k["valu_busy"], k["lane_use"], k.get("wave_cycles_waiting_for_memory_or_barrier", float("nan")),
        traffic["fetched_bytes_per_segment_corrected"], traffic["written_bytes_per_segment"]))
