@@ -901,7 +901,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     std::vector<Wrapped> wrapped;
     struct Run { uint32_t ref = RT_REF_NONE; AABB box = kEmptyBox; bool all = false; }; // all: every ray must enter it
     TimeSpan shutter = {-kInf, kInf}; // ray times for which the bounds of all moving spheres put under the tree hold
-    std::vector<uint32_t> flat_refs, timed_refs;
+    std::vector<uint32_t> flat_refs, timed_refs, tiny_steps;
     uint32_t need = 0;
     int run_rc = RT_OK;
     uint32_t dt_root = RT_REF_NONE, dt_leaves = 0, dt_leaf_need = 0, dt_need_other = 0, dt_need_add = 0; // tree left to the device
@@ -1018,7 +1018,10 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
                     plain = plain && !(RT_REF_TYPE(r) == RT_REF_INST && (f.insts[RT_REF_INDEX(r)].op & RT_INST_LEAF) == 0u);
                     refs.push_back(r);
                 }
-                if (plain) { flat_refs.insert(flat_refs.end(), refs.begin(), refs.end()); return out; }
+                if (plain) { // as steps at depth 1 (RT_REF_STEPS), which the list kernel serves from its lanes' registers
+                    for (uint32_t r : refs) { tiny_steps.push_back(1u); tiny_steps.push_back(r); }
+                    return out;
+                }
                 run_rc = fail(RT_ERR_UNSUPPORTED, "an object of a small world cannot be tested in lock step");
                 return out;
             }
@@ -1216,7 +1219,7 @@ int rt_builder::compile(int world, void** blob_out, size_t* nbytes) {
     // a step of its own per node and waits for the others at every leaf. Its depth-first walk is the same sequence of
     // steps for every ray (bvh.rs:112-122: own box, left, right), so it goes onto the lock-step list as those steps
     // (RT_REF_STEPS), behind the list's other entries as the tree was walked behind them, and the scene has no tree.
-    std::vector<uint32_t> steps;
+    std::vector<uint32_t> steps = tiny_steps;
     if (tree_ref != RT_REF_NONE && dt_root == RT_REF_NONE && timed_refs.empty() && !getenv("RT_NO_LOCKSTEP_TREE")) {
         const size_t kMaxSteps = 48;
         bool ok = true;

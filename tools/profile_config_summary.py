@@ -97,6 +97,6 @@ os.makedirs(os.path.join(src, "out"), exist_ok=True)
 json.dump(traffic, open(os.path.join(src, "out", name + "_extend_hbm_traffic.json"), "w"), indent=1)
 json.dump(sq, open(os.path.join(src, "out", name + "_sq_counters.json"), "w"), indent=1)
 k = sq[kernel]
-print("%s %dx%d @ %d spp: " + kernel + " VALU busy %.3f, lane use %.3f, waiting for memory %.3f; HBM %.1f B fetched (x2) + %.1f B written per segment" %
-      (scene, width, height, spp, k["valu_busy"], k["lane_use"], k.get("wave_cycles_waiting_for_memory_or_barrier", float("nan")),
+print("%s %dx%d @ %d spp: %s VALU busy %.3f, lane use %.3f, waiting for memory %.3f; HBM %.1f B fetched (x2) + %.1f B written per segment" %
+      (scene, width, height, spp, kernel, k["valu_busy"], k["lane_use"], k.get("wave_cycles_waiting_for_memory_or_barrier", float("nan")),
        traffic["fetched_bytes_per_segment_corrected"], traffic["written_bytes_per_segment"]))
