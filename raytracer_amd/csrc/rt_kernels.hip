@@ -1454,6 +1454,14 @@ static int upload_common(rt_context* ctx, const void* src, size_t nbytes, bool s
                 if (RT_REF_TYPE(entries[li]) != RT_REF_STEPS) continue;
                 const uint32_t n_steps = RT_REF_INDEX(entries[li]);
                 if (n_steps > 64u || li + 1u + 2u * (size_t)n_steps >= entries.size()) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_INVALID, "blob: a tree's steps run past the list"); }
+                for (uint32_t j = 0; j < n_steps; ++j) { // a lane's "inside" bits are indexed by these depths
+                    const uint32_t ctrl = entries[li + 1u + 2u * j], operand = entries[li + 2u + 2u * j], d = ctrl & RT_STEP_DEPTH_MASK;
+                    const bool gate = (ctrl & RT_STEP_GATE) != 0u;
+                    if (d < 1u || d > RT_STEP_MAX_DEPTH || (gate && (operand < 1u || operand > s->hdr.exact_boxes.count))) {
+                        hipFree(s->d_blob); delete s;
+                        return ctx_fail(ctx, RT_ERR_INVALID, "blob: a tree's step names a depth or a box that does not exist");
+                    }
+                }
                 s->steps_at = (uint32_t)li; s->n_steps = n_steps;
                 break;
             }

@@ -385,6 +385,19 @@ def test_upload_rejects_bad_blobs(gpu_ctx):
     for bad in (blob[:100], b"\0" * len(blob), blob[:-256]):
         with pytest.raises(RtError):
             gpu_ctx.upload(bad)
+    # a small tree laid out as steps on the lock-step list: a step at depth 0, or a box test naming a box that is not there
+    _, info, blob, _ = util.build_scene("cornell_box")
+    h = __import__("test_abi_and_compiler").header(blob)
+    off, count = h["sections"]["list_entries"]
+    entries = np.frombuffer(blob, dtype="<u4", count=count, offset=off)
+    at = int(h["world_flat"] & 0x03FFFFFF)
+    assert entries[at] >> 28 == 11 and entries[at + 1] & 0x100
+    for word, value in ((at + 1, 0x100), (at + 2, 1000)):
+        bad = bytearray(blob)
+        bad[off + 4 * word:off + 4 * word + 4] = int(value).to_bytes(4, "little")
+        with pytest.raises(RtError):
+            gpu_ctx.upload(bytes(bad))
+    gpu_ctx.upload(blob).close()
 
 
 def test_empty_worlds_on_the_gpu(gpu_ctx):
