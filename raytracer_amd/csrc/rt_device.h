@@ -577,9 +577,10 @@ RT_HD void rt_trav_descend(const Nodes& nodes, RtTrav& s, Stack& st, double t_mi
     while (RT_REF_TYPE(s.cur) == RT_REF_NODE) rt_trav_node_step(nodes, s, st, t_min);
 }
 
-// AHEAD = true: a sphere leaf's record, and the first two steps of the chain it is seen through, are all asked for before
-// any of them is used (one wait instead of up to four in a row; ~20 more registers at that point). For scenes that have
-// such leaves: -1.5 % traversal time on the Book-2 scene; a scene without chains loses 1 - 2.5 % to the same code.
+// AHEAD = true: for a tree whose leaves are all plain - a primitive, a medium, or a primitive named together with a chain of
+// at most two steps (the caller has checked: no list entry, no instance record, no frame to leave ever arrives here). The
+// branches for those are left out, and a leaf's record and the steps of its chain are all asked for before any of them is
+// used (one wait instead of up to four in a row).
 template <bool AHEAD = false, class Stack, class XiFn, class RayFn>
 RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, const XiFn& xi, bool skip_media,
                          const RayFn& world_ray) {
@@ -595,14 +596,14 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
         if (!ok) { s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop(); return; }
     }
 #endif
-    if (type == RT_REF_LIST) { // HittableList: entries in order (hittable_list.rs:45-51)
+    if (!AHEAD && type == RT_REF_LIST) { // HittableList: entries in order (hittable_list.rs:45-51)
         const uint32_t e = sc.list_entries[idx];
         if (e != RT_REF_NONE) {
             st.push(RT_MAKE_REF(RT_REF_LIST, idx + 1u));
             s.cur = e;
             return;
         }
-    } else if (type == RT_REF_POP) { // leave instance idx: back to the ray of its own frame
+    } else if (!AHEAD && type == RT_REF_POP) { // leave instance idx: back to the ray of its own frame
         if (!st.empty()) { // (else nothing is left to test in the frame the lane would return to)
             const RtInst in = sc.insts[idx];
             s.r = rt_ray_to_level(sc, world_ray(), in.parent_inst);
@@ -640,12 +641,10 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
                 const RtChainOp op0 = ch->op[0], op1 = ch->op[1]; // (unused steps of a record are zero-filled)
                 if (n > 0u) moved = rt_apply_chain_op(op0, moved);
                 if (n > 1u) moved = rt_apply_chain_op(op1, moved);
-#pragma unroll 1
-                for (uint32_t k = 2u; k < n && k < (uint32_t)RT_MAX_CHAIN; ++k) moved = rt_apply_chain_op(ch->op[k], moved);
             } else {
                 moved = rt_apply_chain(sc, RT_ILEAF_CHAIN(s.cur), moved);
             }
-        } else if (type == RT_REF_INST) {
+        } else if (!AHEAD && type == RT_REF_INST) {
             RtInst in = sc.insts[idx];
             if ((in.op & RT_INST_LEAF) == 0u) { // a subtree in its own frame: enter it, leave through a POP marker
                 st.push(RT_MAKE_REF(RT_REF_POP, idx));

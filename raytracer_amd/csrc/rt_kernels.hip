@@ -410,10 +410,12 @@ __device__ unsigned long long g_phase[4][48];
 // SPHERE_MEDIA = true: every ConstantMedium of the scene is bounded by a plain sphere.
 // QUERY = true: the rays are a caller's batch (`qb`) instead of the live paths of bounce `it`: same scheduling, same
 // node cache, same leaf rounds; per-ray t_min / t_max and injected medium uniforms.
-// CHAINS = true: the scene has leaves named together with their Translate / RotateY chain (RT_REF_ILEAF), and the
-// instantiation the registers to ask for such a leaf's records all at once (rt_trav_visit<true>); it also carries the
-// short cut for a lock-step list that is one sphere-bounded medium (rt_extend_flat<true>).
-template <bool EXACT_NODES, bool SPHERE_MEDIA, bool QUERY, bool ALL_CACHED, bool CHAINS = false>
+// PLAIN = true: every leaf of the scene's tree is a primitive, a medium, or a primitive named together with a Translate /
+// RotateY chain of at most two steps (RT_REF_ILEAF) - no list, no instance that changes the walk's frame, no linked instance
+// record (rt_scene::plain_leaves, found at upload). The code for those is left out (25 registers less, -9 % kernel time on
+// the Book-2 scene), a leaf's records are asked for all at once (rt_trav_visit<true>), and the lock-step list may be the
+// one sphere-bounded medium of the short cut (rt_extend_flat<true>).
+template <bool EXACT_NODES, bool SPHERE_MEDIA, bool QUERY, bool ALL_CACHED, bool PLAIN = false>
 __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
                                                                uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_pct,
                                                                uint32_t n_cached, uint32_t n_exact_lds, QueryBatch qb) {
@@ -505,8 +507,8 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
                     // the world entries every ray is tested against, by the lanes that just took a ray, in lock step
                     HeldRay held;
                     held.r = &s.r;
-                    rt_extend_flat<CHAINS>(sc, held, t_min, s.best, xi_of(id, path), skip_media);
-                    if (CHAINS || sc.world_tree != RT_REF_NONE) s.slab = rt_slab_of<EXACT_NODES>(s.r, sc.node_extent); // (a scene without a tree: none of the CHAINS instantiations is its kernel)
+                    rt_extend_flat<PLAIN>(sc, held, t_min, s.best, xi_of(id, path), skip_media);
+                    if (PLAIN || sc.world_tree != RT_REF_NONE) s.slab = rt_slab_of<EXACT_NODES>(s.r, sc.node_extent); // (a scene without a tree: none of the PLAIN instantiations is its kernel)
                     s.cur = sc.world_tree;
                     st.clear();
                     active = true;
@@ -556,11 +558,11 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             if constexpr (QUERY) {
                 QueryRay ray_of;
                 ray_of.q = qb.rays + path;
-                rt_trav_visit<CHAINS>(sc, s, st, t_min, xi_of(id, path), skip_media, ray_of);
+                rt_trav_visit<PLAIN>(sc, s, st, t_min, xi_of(id, path), skip_media, ray_of);
             } else {
                 SlotRay ray_of;
                 ray_of.rec = rays + path;
-                rt_trav_visit<CHAINS>(sc, s, st, t_min, xi_of(id, path), skip_media, ray_of);
+                rt_trav_visit<PLAIN>(sc, s, st, t_min, xi_of(id, path), skip_media, ray_of);
             }
         }
         if (active && s.cur == RT_REF_NONE) { // finished: publish the closest hit
@@ -1042,6 +1044,7 @@ struct rt_scene {
     uint32_t bucket_mask = 0;              // shading buckets some material of the scene falls into
     bool sphere_media = true;              // every medium is bounded by a plain sphere (no instance, no other primitive)
     bool tree_built = false;               // rt_scene_build_tree_device has replaced the stand-in tree
+    bool plain_leaves = false;             // below the world's tree nothing changes frames or opens a list: every leaf is a primitive, a medium, or a primitive named with a chain of at most two steps
     uint32_t steps_at = 0u, n_steps = 0u;  // a small tree's steps on the lock-step list: index of their RT_REF_STEPS entry, their number (0: none)
     // [0]: hdr.world_flat, [1]: hdr.world_flat_any_time - the list's one medium and its sphere when that is all the list holds
     struct OneMedium { uint32_t ref = 0u; RtMedium medium; RtSphere sphere; } one_medium[2];
@@ -1255,7 +1258,7 @@ struct ExtendLaunch {
 };
 // `force`: bit 0 = the instantiation with exact f64 box tests even if the scene has no node that needs them, bit 1 = the
 // one with the general medium-boundary code even if every medium is bounded by a sphere (both are valid for any scene),
-// bit 2 = the tree kernel even for a scene without a tree.
+// bit 2 = the tree kernel even for a scene without a tree, bit 3 = not the instantiation for trees with plain leaves.
 int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t force, ExtendLaunch* out) {
     const uint32_t stack_cap = sc->hdr.stack_need;
     // Persistent waves, one workgroup per CU: its LDS holds the traversal stacks and, in what is left, the first
@@ -1280,13 +1283,12 @@ int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t f
 #undef RT_EXT_ROW
     const bool all_cached = n_cached == sc->hdr.nodes.count; // every node of the scene has a place in LDS
     out->kernel = table[exact_nodes][sphere_media][query][all_cached];
-    // leaves named with their chain, in an instantiation that has the registers for it: their records fetched together
-    // (not for a scene without a tree: its lock-step list may hold a small tree's steps, which that instantiation's list walk
-    // leaves out)
-    if (sc->hdr.chains.count != 0u && !exact_nodes && sphere_media && sc->hdr.world_tree != RT_REF_NONE) {
-        static const ExtendKernel with_chains[2][2] = {{k_extend_tree<false, true, false, false, true>, k_extend_tree<false, true, false, true, true>},
+    // a tree with plain leaves: the instantiation without the code for lists and frame changes (not for a scene without a
+    // tree: its lock-step list may hold a small tree's steps, which that instantiation's list walk leaves out)
+    if (sc->plain_leaves && !exact_nodes && sphere_media && sc->hdr.world_tree != RT_REF_NONE && !(force & 8u)) {
+        static const ExtendKernel plain_tree[2][2] = {{k_extend_tree<false, true, false, false, true>, k_extend_tree<false, true, false, true, true>},
                                                        {k_extend_tree<false, true, true, false, true>, k_extend_tree<false, true, true, true, true>}};
-        out->kernel = with_chains[query][all_cached];
+        out->kernel = plain_tree[query][all_cached];
     }
     out->list_only = sc->hdr.world_tree == RT_REF_NONE && !(force & 4u);
     if (out->list_only) { // nothing to walk per lane
@@ -1466,6 +1468,22 @@ static int upload_common(rt_context* ctx, const void* src, size_t nbytes, bool s
                 break;
             }
         }
+        // What the leaves of the world's tree are: if none of them is a list, a frame-changing instance or a linked instance
+        // record, the traversal kernel runs an instantiation without the code for those (they cost it 25 registers).
+        // (a tree that the device builds later keeps its leaves, rt_tree_build.hip only rearranges them)
+        if (RT_REF_TYPE(s->hdr.world_tree) == RT_REF_NODE && s->hdr.max_chain <= 2u && s->hdr.nodes.count <= (256u << 20) / sizeof(RtNode)) {
+            std::vector<RtNode> nodes(s->hdr.nodes.count);
+            e = hipMemcpy(nodes.data(), (const uint8_t*)src + s->hdr.nodes.offset, nodes.size() * sizeof(RtNode), kind);
+            if (e != hipSuccess) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_NO_DEVICE, "read nodes", e); }
+            bool plain = true;
+            for (const RtNode& n : nodes)
+                for (uint32_t c : {n.c0, n.c1}) {
+                    const uint32_t ty = RT_REF_TYPE(c);
+                    plain = plain && (ty == RT_REF_NONE || ty == RT_REF_NODE || ty == RT_REF_SPHERE || ty == RT_REF_MSPHERE || ty == RT_REF_RECT ||
+                                      ty == RT_REF_BOX || ty == RT_REF_MEDIUM || ty == RT_REF_ILEAF);
+                }
+            s->plain_leaves = plain;
+        }
         s->choose_flat(1u); // (make_view names the any-time list)
     }
     *out = s;
@@ -1560,7 +1578,7 @@ int rt_trace_first_hit(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays
 int rt_trace_first_hit_wavefront(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays, size_t n, const double* medium_xi,
                                  rt_hit* out, uint32_t variant) try {
     if (!ctx) return RT_ERR_INVALID;
-    if (!sc || (!rays && n) || (!out && n) || n > 0x7FFFFFFFu || variant > 7u) return ctx_fail(ctx, RT_ERR_INVALID, "trace_first_hit_wavefront: bad argument");
+    if (!sc || (!rays && n) || (!out && n) || n > 0x7FFFFFFFu || variant > 15u) return ctx_fail(ctx, RT_ERR_INVALID, "trace_first_hit_wavefront: bad argument");
     if (n == 0) return RT_OK;
     for (size_t i = 0; i < n; ++i)
         if (rays[i].time < sc->hdr.valid0 || rays[i].time > sc->hdr.valid1)
