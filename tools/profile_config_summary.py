@@ -81,8 +81,8 @@ sq_rows = per_dispatch(find("sqx_counter_collection.csv"))
 
 def one(d):
     cycles = d["SQ_BUSY_CYCLES"] / 32.0
-    o = {"kernel_cycles": cycles, "valu_instructions": d["SQ_INSTS_VALU"], "valu_busy": 4.0 * d["SQ_INSTS_VALU"] / (1024.0 * cycles),
-         "lane_use": d["SQ_THREAD_CYCLES_VALU"] / (64.0 * d["SQ_ACTIVE_INST_VALU"])}
+    o = {"kernel_cycles": cycles, "valu_instructions": d["SQ_INSTS_VALU"], "valu_busy": 4.0 * d["SQ_INSTS_VALU"] / (1024.0 * max(cycles, 1.0)),
+         "lane_use": d["SQ_THREAD_CYCLES_VALU"] / (64.0 * max(d["SQ_ACTIVE_INST_VALU"], 1.0))}  # (a launch that found no rays counts nothing)
     if d.get("SQ_WAVE_CYCLES"):
         o["wave_cycles_waiting_to_issue"] = d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"]
         o["wave_cycles_waiting_for_memory_or_barrier"] = d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"]
