@@ -1056,16 +1056,23 @@ RT_HD V3 rt_tex_noise_value(const DScene& sc, const RtTexture& t, V3 p) {
 }
 // Texture::value for SolidColor / CheckerTexture / NoiseTexture / ImageTexture
 // (texture.rs:23-27, 46-54, 73-79, 105-127).
+// KINDS: which kinds of computed texture the scene holds at all, when the caller knows (bit RT_TEX_CHECKER, RT_TEX_NOISE,
+// RT_TEX_IMAGE): the code for the others is left out - a kernel that shades a checker of two colours then carries neither
+// the Perlin noise nor the sphere's (u, v) for an image, and needs half the registers.
+#define RT_TEX_KINDS_ALL ((1u << RT_TEX_CHECKER) | (1u << RT_TEX_NOISE) | (1u << RT_TEX_IMAGE))
+template <uint32_t KINDS = RT_TEX_KINDS_ALL>
 RT_HD V3 rt_tex_value(const DScene& sc, uint32_t tex, double u, double v, V3 p) {
     RtTexture t = sc.textures[tex];
+    if (KINDS & (1u << RT_TEX_CHECKER)) {
 #pragma unroll 1
-    for (int guard = 0; guard < 8 && t.type == RT_TEX_CHECKER; ++guard) {
-        double sines = sin(10.0 * p.x) * sin(10.0 * p.y) * sin(10.0 * p.z);
-        t = sc.textures[sines < 0.0 ? t.b : t.a];
+        for (int guard = 0; guard < 8 && t.type == RT_TEX_CHECKER; ++guard) {
+            double sines = sin(10.0 * p.x) * sin(10.0 * p.y) * sin(10.0 * p.z);
+            t = sc.textures[sines < 0.0 ? t.b : t.a];
+        }
     }
     if (t.type == RT_TEX_SOLID) return v3(t.p[0], t.p[1], t.p[2]);
-    if (t.type == RT_TEX_NOISE) return rt_tex_noise_value(sc, t, p);
-    if (t.type == RT_TEX_IMAGE) {
+    if ((KINDS & (1u << RT_TEX_NOISE)) && t.type == RT_TEX_NOISE) return rt_tex_noise_value(sc, t, p);
+    if ((KINDS & (1u << RT_TEX_IMAGE)) && t.type == RT_TEX_IMAGE) {
         const uint64_t width = t.b, height = t.c;
         double u_ = rt_clamp(u, 0.0, 1.0);
         double v_ = 1.0 - rt_clamp(v, 0.0, 1.0);
@@ -1129,7 +1136,7 @@ RT_HD double rt_reflectance(double cosine, double ref_idx) {
 // MAT = the material type when the caller knows it at compile time (the per-material shade kernels), which prunes
 // the other four bodies; RT_MAT_COUNT = decide from m.type at run time. SOLID / NOISE = the caller knows the texture is a
 // SolidColor / a NoiseTexture.
-template <uint32_t MAT, bool SOLID = false, bool NOISE = false>
+template <uint32_t MAT, bool SOLID = false, bool NOISE = false, uint32_t KINDS = RT_TEX_KINDS_ALL>
 RT_HD ShadeOut rt_shade_as(const DScene& sc, const RtMaterial& m, const Ray& r_in, const HitRec& rec, const Sampler& smp) {
     ShadeOut o;
     o.emitted = v3(0.0, 0.0, 0.0);
@@ -1146,7 +1153,7 @@ RT_HD ShadeOut rt_shade_as(const DScene& sc, const RtMaterial& m, const Ray& r_i
     if (type == RT_MAT_METAL || type == RT_MAT_DIELECTRIC) unit_in = v3_unit(r_in.d);
     V3 colour = v3(0.0, 0.0, 0.0); // Texture::value of the material's texture (Lambertian / Isotropic albedo, DiffuseLight emit)
     if (type == RT_MAT_LAMBERTIAN || type == RT_MAT_DIFFUSE_LIGHT || type == RT_MAT_ISOTROPIC)
-        colour = SOLID ? v3(m.p[1], m.p[2], m.p[3]) : NOISE ? rt_tex_noise_value(sc, sc.textures[m.tex], rec.p) : rt_tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+        colour = SOLID ? v3(m.p[1], m.p[2], m.p[3]) : NOISE ? rt_tex_noise_value(sc, sc.textures[m.tex], rec.p) : rt_tex_value<KINDS>(sc, m.tex, rec.u, rec.v, rec.p);
     switch (type) {
     case RT_MAT_LAMBERTIAN: { // material.rs:41-59; random_unit_vector = unit_vector(random_in_unit_sphere), vec3.rs:82-84
         V3 scatter_direction = rec.normal + v3_unit(in_sphere);

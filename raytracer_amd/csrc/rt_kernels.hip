@@ -716,7 +716,8 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4
 }
 
 // emitted + scatter (main.rs:60-70) for every path of iteration `it` that hit a material of type MAT.
-template <uint32_t BUCKET>
+// KINDS: the kinds of computed texture the scene holds (rt_tex_value), RT_TEX_KINDS_ALL when the launch does not care.
+template <uint32_t BUCKET, uint32_t KINDS = RT_TEX_KINDS_ALL>
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it) {
     constexpr uint32_t MAT = rt_bucket_material(BUCKET);
     constexpr bool SOLID = rt_bucket_solid(BUCKET);
@@ -749,10 +750,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DScene sc, PassInfo pi, Path
             const RtHitMeta g = rt_hit_meta(sc, h);
             const RtMaterial m = sc.materials[g.material];
             const RtHitLevels lv = rt_hit_levels(sc, g.parent);
-            const bool uv = (SOLID || MAT == RT_MAT_METAL || MAT == RT_MAT_DIELECTRIC || BUCKET == RT_BUCKET_LAMBERTIAN_NOISE) ? false : rt_material_reads_uv(sc, m);
+            // (u, v) are read by an image only - where the scene has one, possibly below a checker
+            const bool uv = (SOLID || MAT == RT_MAT_METAL || MAT == RT_MAT_DIELECTRIC || BUCKET == RT_BUCKET_LAMBERTIAN_NOISE || !(KINDS & (1u << RT_TEX_IMAGE)))
+                                ? false : rt_material_reads_uv(sc, m);
             const HitRec rec = rt_reconstruct(sc, r, h, uv, g, lv);
             const Sampler smp = slot_sampler(pi, id, it);
-            const ShadeOut o = rt_shade_as<MAT, SOLID, BUCKET == RT_BUCKET_LAMBERTIAN_NOISE>(sc, m, r, rec, smp);
+            const ShadeOut o = rt_shade_as<MAT, SOLID, BUCKET == RT_BUCKET_LAMBERTIAN_NOISE, KINDS>(sc, m, r, rec, smp);
             // a path that used its last bounce adds nothing more: ray_color(depth <= 0) is black (main.rs:52-54)
             if (o.did_scatter && it + 1u < pi.max_depth) {
                 alive = true;
@@ -1044,6 +1047,7 @@ struct rt_scene {
     uint32_t bucket_mask = 0;              // shading buckets some material of the scene falls into
     bool sphere_media = true;              // every medium is bounded by a plain sphere (no instance, no other primitive)
     bool tree_built = false;               // rt_scene_build_tree_device has replaced the stand-in tree
+    uint32_t tex_kinds = 0u;               // bit t: the texture table holds a texture of type t (RtTextureType)
     bool plain_leaves = false;             // below the world's tree nothing changes frames or opens a list: every leaf is a primitive, a medium, or a primitive named with a chain of at most two steps
     uint32_t steps_at = 0u, n_steps = 0u;  // a small tree's steps on the lock-step list: index of their RT_REF_STEPS entry, their number (0: none)
     // [0]: hdr.world_flat, [1]: hdr.world_flat_any_time - the list's one medium and its sphere when that is all the list holds
@@ -1313,7 +1317,20 @@ void launch_shade(rt_context* ctx, const rt_scene* sc, const PassInfo& pi, const
                   uint32_t grid, EventTimer& tm) {
     if (!(sc->bucket_mask >> BUCKET & 1u)) return; // no material of the scene is shaded by this kernel
     size_t a = tm.begin();
-    hipLaunchKernelGGL(k_shade<BUCKET>, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, sc->view, pi, pb, qs, it);
+    constexpr uint32_t kChecker = 1u << RT_TEX_CHECKER, kImage = 1u << RT_TEX_IMAGE;
+    // A scene whose only computed textures are checkers (a ground of two colours) or, Lambertian over noise having a bucket of
+    // its own, images (a globe) runs the kernel without the code for the other kinds.
+    bool launched = false;
+    if constexpr (BUCKET != RT_BUCKET_LAMBERTIAN_NOISE) {
+        if (sc->tex_kinds == kChecker) {
+            hipLaunchKernelGGL((k_shade<BUCKET, kChecker>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, sc->view, pi, pb, qs, it);
+            launched = true;
+        } else if ((sc->tex_kinds & ~(1u << RT_TEX_NOISE)) == kImage && BUCKET == RT_BUCKET_LAMBERTIAN_TEX) {
+            hipLaunchKernelGGL((k_shade<BUCKET, kImage>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, sc->view, pi, pb, qs, it);
+            launched = true;
+        }
+    }
+    if (!launched) hipLaunchKernelGGL(k_shade<BUCKET>, dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, sc->view, pi, pb, qs, it);
     tm.end(a, 2 + (int)rt_bucket_material(BUCKET));
 }
 
@@ -1412,6 +1429,7 @@ static int upload_common(rt_context* ctx, const void* src, size_t nbytes, bool s
         if (!mats.empty()) e = hipMemcpy(mats.data(), b + s->hdr.materials.offset, mats.size() * sizeof(RtMaterial), kind);
         if (e == hipSuccess && !texs.empty()) e = hipMemcpy(texs.data(), b + s->hdr.textures.offset, texs.size() * sizeof(RtTexture), kind);
         if (e != hipSuccess) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_NO_DEVICE, "read material table", e); }
+        for (const RtTexture& t : texs) if (t.type <= RT_TEX_IMAGE && t.type != RT_TEX_SOLID) s->tex_kinds |= 1u << t.type;
         for (const RtMaterial& m : mats) {
             if (m.type >= RT_MAT_COUNT) { hipFree(s->d_blob); delete s; return ctx_fail(ctx, RT_ERR_INVALID, "blob: unknown material type"); }
             const bool textured = m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_DIFFUSE_LIGHT || m.type == RT_MAT_ISOTROPIC;
