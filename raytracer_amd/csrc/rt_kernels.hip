@@ -7,11 +7,14 @@
 //   per bounce it = 0 .. max_depth-1
 //     k_extend_tree          closest hit of every live path: persistent waves, one 1024-thread workgroup per CU,
 //                            per-lane stacks and the top of the node array in LDS
+//     (k_extend_list          instead, for a scene whose world is all on the lock-step list: one ray per lane, the list
+//                            front to back)
 //     k_shade_main           misses take the background and end; hits on materials with a plain colour: rebuild the
 //                            hit record, emitted + scatter, and write the surviving path's next ray and throughput
 //                            as a record of the next bounce (one atomic per workgroup); hits on computed textures
 //                            (Perlin, image, checker) are queued by material type
-//     k_shade<bucket>        the same shading for one queue of computed-texture hits
+//     k_shade<bucket, kinds> the same shading for one queue of computed-texture hits, with the code for the kinds of
+//                            texture the scene holds
 //   k_accumulate             per pixel, add its S sample radiances in sample order to the f64 sum buffer
 //
 // Path state per bounce is dense: a 64-byte ray record (with the path's slot and pixel), a 24-byte throughput record
