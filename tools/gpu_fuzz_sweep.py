@@ -34,9 +34,15 @@ for seed in range(lo, hi):
         rng = np.random.default_rng(1000 + seed)
         rays = util.random_rays(rng, 4000, any_time=bool(flags & 4))
         xi = rng.random((len(rays), osc.n_media)) if osc.n_media else None
-        rep = util.first_hit_report(ctx.trace_first_hit(scene, rays, xi), osc.trace_first_hit(rays, xi))
+        lane = ctx.trace_first_hit(scene, rays, xi)
+        rep = util.first_hit_report(lane, osc.trace_first_hit(rays, xi))
         n += 1
         ok = rep["prim_match"] >= 0.9995 and rep["t_rel_max"] <= 1e-5 and rep["t_bit_equal"] >= 0.95
+        # the renderer's closest-hit kernels (the one the scene gets, and the general tree kernel): the same records
+        for variant in (0, 12):
+            if ctx.trace_first_hit(scene, rays, xi, wavefront=variant).tobytes() != lane.tobytes():
+                ok = False
+                print("KERNELS DISAGREE", seed, flags, variant, flush=True)
         if not flags & 4:
             p = api.make_params(40, 30, max_depth=12, background=(0.7, 0.8, 1.0), seed=77 + seed, spp_per_pass=3)
             got = ctx.render(scene, cam, p, 4)
