@@ -207,13 +207,10 @@ RT_HD bool rt_aabb_hit(const Bound (&lo)[3], const Bound (&hi)[3], const Ray& r,
 // would have rejected changes nothing but the work): f32 throughout, every rounding taken outwards. A NaN slab
 // distance (0 * inf, inf - inf: a ray parallel to the slab) is ignored by fmaxf / fminf, which errs towards entering.
 // t_min rounded down, t_max rounded up; e0, e1: entry distances, good enough to choose the nearer child.
-RT_HD void rt_node_boxes_f32(const RtNode& n, const RtSlab& k, float t_min, float t_max, bool& h0, bool& h1, float& e0, float& e1) {
-    const float n0x = k.nx ? n.hi0[0] : n.lo0[0], f0x = k.nx ? n.lo0[0] : n.hi0[0];
-    const float n0y = k.ny ? n.hi0[1] : n.lo0[1], f0y = k.ny ? n.lo0[1] : n.hi0[1];
-    const float n0z = k.nz ? n.hi0[2] : n.lo0[2], f0z = k.nz ? n.lo0[2] : n.hi0[2];
-    const float n1x = k.nx ? n.hi1[0] : n.lo1[0], f1x = k.nx ? n.lo1[0] : n.hi1[0];
-    const float n1y = k.ny ? n.hi1[1] : n.lo1[1], f1y = k.ny ? n.lo1[1] : n.hi1[1];
-    const float n1z = k.nz ? n.hi1[2] : n.lo1[2], f1z = k.nz ? n.lo1[2] : n.hi1[2];
+// (the arithmetic, given each box's bound on the side the ray enters (n) and leaves (f) by, per axis)
+RT_HD void rt_node_boxes_f32_picked(float n0x, float n0y, float n0z, float f0x, float f0y, float f0z, float n1x, float n1y, float n1z,
+                                    float f1x, float f1y, float f1z, const RtSlab& k, float t_min, float t_max, bool& h0, bool& h1,
+                                    float& e0, float& e1) {
     const float a0x = __builtin_fmaf(n0x, k.ix, -k.cnx), a0y = __builtin_fmaf(n0y, k.iy, -k.cny), a0z = __builtin_fmaf(n0z, k.iz, -k.cnz);
     const float b0x = __builtin_fmaf(f0x, k.ix, -k.cfx), b0y = __builtin_fmaf(f0y, k.iy, -k.cfy), b0z = __builtin_fmaf(f0z, k.iz, -k.cfz);
     const float a1x = __builtin_fmaf(n1x, k.ix, -k.cnx), a1y = __builtin_fmaf(n1y, k.iy, -k.cny), a1z = __builtin_fmaf(n1z, k.iz, -k.cnz);
@@ -224,6 +221,15 @@ RT_HD void rt_node_boxes_f32(const RtNode& n, const RtSlab& k, float t_min, floa
     const float x1 = __builtin_fminf(__builtin_fminf(b1x, b1y), __builtin_fminf(b1z, t_max));
     h0 = !(x0 < e0);
     h1 = !(x1 < e1);
+}
+RT_HD void rt_node_boxes_f32(const RtNode& n, const RtSlab& k, float t_min, float t_max, bool& h0, bool& h1, float& e0, float& e1) {
+    const float n0x = k.nx ? n.hi0[0] : n.lo0[0], f0x = k.nx ? n.lo0[0] : n.hi0[0];
+    const float n0y = k.ny ? n.hi0[1] : n.lo0[1], f0y = k.ny ? n.lo0[1] : n.hi0[1];
+    const float n0z = k.nz ? n.hi0[2] : n.lo0[2], f0z = k.nz ? n.lo0[2] : n.hi0[2];
+    const float n1x = k.nx ? n.hi1[0] : n.lo1[0], f1x = k.nx ? n.lo1[0] : n.hi1[0];
+    const float n1y = k.ny ? n.hi1[1] : n.lo1[1], f1y = k.ny ? n.lo1[1] : n.hi1[1];
+    const float n1z = k.nz ? n.hi1[2] : n.lo1[2], f1z = k.nz ? n.lo1[2] : n.hi1[2];
+    rt_node_boxes_f32_picked(n0x, n0y, n0z, f0x, f0y, f0z, n1x, n1y, n1z, f1x, f1y, f1z, k, t_min, t_max, h0, h1, e0, e1);
 }
 // One node record as four 16-byte loads (records are 64-byte aligned).
 RT_HD RtNode rt_load_node(const RtNode* p) {

@@ -409,6 +409,51 @@ __device__ unsigned long long g_phase[4][48];
 #define RT_PHASE_CLOCK(var) ((void)0)
 #define RT_PHASE_SPAN(k, a, b) ((void)0)
 #endif
+// ---- node records as fourteen arrays, fetched by the ray's signs ----
+// A box step picks, per axis, the bound the ray enters by and the one it leaves by: twelve selects on the 64-byte record.
+// Where every node is in LDS and the count allows, the records are kept instead as fourteen arrays of ARRAYS words each
+// (lo0 xyz, hi0 xyz, lo1 xyz, hi1 xyz, child 0, child 1), and a lane holds six LDS addresses - for each axis the array its
+// ray enters by and the one it leaves by, fixed when it takes the ray. A step is then six address adds and six reads of two
+// words (box 0's and, 6 * ARRAYS words on, box 1's: ds_read2st64_b32 where the distance allows) instead of four adds, four
+// 16-byte reads and twelve selects; the arithmetic on the picked bounds is rt_node_boxes_f32's.
+typedef const __attribute__((address_space(3))) float* LdsF32;
+typedef const __attribute__((address_space(3))) uint32_t* LdsU32;
+template <int ARRAYS>
+struct SignedNodes {
+    uint32_t near_at[3], far_at[3]; // LDS byte addresses of word 0 of the arrays this lane's ray enters / leaves by
+    __device__ void take(uint32_t base, const RtSlab& k) { // base: LDS byte address of the first array
+        const bool neg[3] = {k.nx, k.ny, k.nz};
+#pragma unroll
+        for (uint32_t a = 0u; a < 3u; ++a) {
+            near_at[a] = base + 4u * (uint32_t)ARRAYS * (neg[a] ? 3u + a : a);
+            far_at[a] = base + 4u * (uint32_t)ARRAYS * (neg[a] ? a : 3u + a);
+        }
+    }
+};
+template <int ARRAYS>
+__device__ __forceinline__ void rt_node_step_signed(const SignedNodes<ARRAYS>& at, uint32_t child_base, RtTrav& s, LdsStack& st, double t_min) {
+    const uint32_t under = st.prefetch();
+    const uint32_t i4 = RT_REF_INDEX(s.cur) << 2;
+    constexpr uint32_t kBox1 = 6u * (uint32_t)ARRAYS;
+    const LdsF32 nx = (LdsF32)(uintptr_t)(at.near_at[0] + i4), ny = (LdsF32)(uintptr_t)(at.near_at[1] + i4), nz = (LdsF32)(uintptr_t)(at.near_at[2] + i4);
+    const LdsF32 fx = (LdsF32)(uintptr_t)(at.far_at[0] + i4), fy = (LdsF32)(uintptr_t)(at.far_at[1] + i4), fz = (LdsF32)(uintptr_t)(at.far_at[2] + i4);
+    const LdsU32 kids = (LdsU32)(uintptr_t)(child_base + i4);
+    const float n0x = nx[0], n1x = nx[kBox1], n0y = ny[0], n1y = ny[kBox1], n0z = nz[0], n1z = nz[kBox1];
+    const float f0x = fx[0], f1x = fx[kBox1], f0y = fy[0], f1y = fy[kBox1], f0z = fz[0], f1z = fz[kBox1];
+    const uint32_t c0 = kids[0], c1 = kids[ARRAYS];
+    RT_VISIT(0u);
+    const float lo = (float)t_min, hi = (float)s.best.t; // widened by an ulp each: the conversions round to nearest
+    bool h0, h1;
+    float e0, e1;
+    rt_node_boxes_f32_picked(n0x, n0y, n0z, f0x, f0y, f0z, n1x, n1y, n1z, f1x, f1y, f1z, s.slab, lo - __builtin_fabsf(lo) * 0x1p-23f,
+                             hi + __builtin_fabsf(hi) * 0x1p-23f, h0, h1, e0, e1);
+    const bool swap = e1 < e0;
+    h1 = h1 && c1 != RT_REF_NONE;
+    const bool both = h0 && h1;
+    const uint32_t go = both ? (swap ? c1 : c0) : (h0 ? c0 : c1);
+    s.cur = st.node_step(both, h0 || h1, go, swap ? c0 : c1, under);
+}
+
 // EXACT_NODES = false: the scene has no node whose box tests must reproduce the reference's f64 arithmetic.
 // SPHERE_MEDIA = true: every ConstantMedium of the scene is bounded by a plain sphere.
 // QUERY = true: the rays are a caller's batch (`qb`) instead of the live paths of bounce `it`: same scheduling, same
@@ -418,7 +463,9 @@ __device__ unsigned long long g_phase[4][48];
 // record (rt_scene::plain_leaves, found at upload). The code for those is left out (25 registers less, -9 % kernel time on
 // the Book-2 scene), a leaf's records are asked for all at once (rt_trav_visit<true>), and the lock-step list may be the
 // one sphere-bounded medium of the short cut (rt_extend_flat<true>).
-template <bool EXACT_NODES, bool SPHERE_MEDIA, bool QUERY, bool ALL_CACHED, bool PLAIN = false>
+// ARRAYS > 0: the node records in LDS as fourteen arrays of that many words (rt_node_step_signed); needs PLAIN, ALL_CACHED,
+// no exact nodes, and at most ARRAYS nodes.
+template <bool EXACT_NODES, bool SPHERE_MEDIA, bool QUERY, bool ALL_CACHED, bool PLAIN = false, int ARRAYS = 0>
 __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
                                                                uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_pct,
                                                                uint32_t n_cached, uint32_t n_exact_lds, QueryBatch qb) {
@@ -439,7 +486,9 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
         return xi;
     };
     // queue positions handed out in this workgroup so far: the 16 bytes behind the node records
-    uint32_t& blk_taken = *(uint32_t*)(lds_tree + (size_t)stack_cap * blockDim.x / 4u + (size_t)n_cached * 4u);
+    static_assert(ARRAYS == 0 || (PLAIN && ALL_CACHED && !EXACT_NODES && ARRAYS % 64 == 0), "the array layout is for small plain trees");
+    const size_t node_words = ARRAYS > 0 ? (size_t)14u * (size_t)ARRAYS : (size_t)n_cached * 16u;
+    uint32_t& blk_taken = *(uint32_t*)(lds_tree + (size_t)stack_cap * blockDim.x / 4u + node_words / 4u);
     if (threadIdx.x == 0u) blk_taken = 0u;
     LdsStack st;
     st.init((uint32_t*)lds_tree + threadIdx.x, stack_cap, blockDim.x, qs.error_flag);
@@ -447,7 +496,14 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
     {
         uint4* cache = lds_tree + (size_t)stack_cap * blockDim.x / 4u;
         const uint4* src = (const uint4*)sc.nodes;
-        for (uint32_t i = threadIdx.x; i < n_cached * 4u; i += blockDim.x) cache[CachedNodes<ALL_CACHED>::place(i >> 2, i & 3u, n_cached)] = src[i];
+        if constexpr (ARRAYS > 0) { // word f of record i -> array f (the two words of padding are left out)
+            uint32_t* arrays = (uint32_t*)cache;
+            const uint32_t* words = (const uint32_t*)sc.nodes;
+            for (uint32_t w = threadIdx.x; w < n_cached * 16u; w += blockDim.x)
+                if ((w & 15u) < 14u) arrays[(w & 15u) * (uint32_t)ARRAYS + (w >> 4)] = words[w];
+        } else {
+            for (uint32_t i = threadIdx.x; i < n_cached * 4u; i += blockDim.x) cache[CachedNodes<ALL_CACHED>::place(i >> 2, i & 3u, n_cached)] = src[i];
+        }
         nodes.lds = (LdsU4)cache;
         nodes.n_cached = n_cached;
         nodes.global = sc.nodes;
@@ -466,6 +522,10 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
     RtTrav s;
     s.cur = RT_REF_NONE;
     s.best.t = RT_INF; s.best.ref = RT_REF_NONE; s.best.aux = 0u;
+    // (the array layout: where the arrays start in LDS, and the six this lane's ray reads its bounds from)
+    const uint32_t arrays_at = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)((uint32_t*)lds_tree + (size_t)stack_cap * blockDim.x);
+    SignedNodes<(ARRAYS > 0 ? ARRAYS : 64)> picked;
+    for (int a = 0; a < 3; ++a) { picked.near_at[a] = arrays_at; picked.far_at[a] = arrays_at; }
     PathId id;
     id.slot = 0u; id.pixel = 0u;
     uint32_t path = 0u;
@@ -512,6 +572,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
                     held.r = &s.r;
                     rt_extend_flat<PLAIN>(sc, held, t_min, s.best, xi_of(id, path), skip_media);
                     if (PLAIN || sc.world_tree != RT_REF_NONE) s.slab = rt_slab_of<EXACT_NODES>(s.r, sc.node_extent); // (a scene without a tree: none of the PLAIN instantiations is its kernel)
+                    if constexpr (ARRAYS > 0) picked.take(arrays_at, s.slab);
                     s.cur = sc.world_tree;
                     st.clear();
                     active = true;
@@ -538,10 +599,16 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             if (m_node == 0ull) break;
             if (n_active - (uint32_t)__popcll(m_node) >= leaf_now) break;
             RT_PHASE_ADD(3, 1); RT_PHASE_ADD(4, __popcll(m_node));
-            if (at_node) rt_trav_node_step<EXACT_NODES>(nodes, s, st, t_min);
-            // a second step before the next look at the wave: the two ballots above cost a sixth of a step (-3.6 % kernel
-            // time; a third and fourth step bring nothing more, measured again with the relative leaf threshold)
-            if (RT_REF_TYPE(s.cur) == RT_REF_NODE) rt_trav_node_step<EXACT_NODES>(nodes, s, st, t_min);
+            if constexpr (ARRAYS > 0) {
+                const uint32_t kids_at = arrays_at + 4u * 12u * (uint32_t)ARRAYS;
+                if (at_node) rt_node_step_signed<ARRAYS>(picked, kids_at, s, st, t_min);
+                if (RT_REF_TYPE(s.cur) == RT_REF_NODE) rt_node_step_signed<ARRAYS>(picked, kids_at, s, st, t_min);
+            } else {
+                if (at_node) rt_trav_node_step<EXACT_NODES>(nodes, s, st, t_min);
+                // a second step before the next look at the wave: the two ballots above cost a sixth of a step (-3.6 % kernel
+                // time; a third and fourth step bring nothing more, measured again with the relative leaf threshold)
+                if (RT_REF_TYPE(s.cur) == RT_REF_NODE) rt_trav_node_step<EXACT_NODES>(nodes, s, st, t_min);
+            }
         }
         RT_PHASE_CLOCK(c_nodes1);
         RT_PHASE_SPAN(42, c_nodes0, c_nodes1);
@@ -1265,7 +1332,8 @@ struct ExtendLaunch {
 };
 // `force`: bit 0 = the instantiation with exact f64 box tests even if the scene has no node that needs them, bit 1 = the
 // one with the general medium-boundary code even if every medium is bounded by a sphere (both are valid for any scene),
-// bit 2 = the tree kernel even for a scene without a tree, bit 3 = not the instantiation for trees with plain leaves.
+// bit 2 = the tree kernel even for a scene without a tree, bit 3 = not the instantiation for trees with plain leaves, bit 4 = not the
+// array layout of the node records in LDS.
 int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t force, ExtendLaunch* out) {
     const uint32_t stack_cap = sc->hdr.stack_need;
     // Persistent waves, one workgroup per CU: its LDS holds the traversal stacks and, in what is left, the first
@@ -1296,6 +1364,15 @@ int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t f
         static const ExtendKernel plain_tree[2][2] = {{k_extend_tree<false, true, false, false, true>, k_extend_tree<false, true, false, true, true>},
                                                        {k_extend_tree<false, true, true, false, true>, k_extend_tree<false, true, true, true, true>}};
         out->kernel = plain_tree[query][all_cached];
+        // every node in LDS and few enough of them: the records as fourteen arrays (rt_node_step_signed), if that fits too
+        static const ExtendKernel arrays512[2] = {k_extend_tree<false, true, false, true, true, 512>, k_extend_tree<false, true, true, true, true, 512>};
+        static const ExtendKernel arrays1536[2] = {k_extend_tree<false, true, false, true, true, 1536>, k_extend_tree<false, true, true, true, true, 1536>};
+        const size_t count = sc->hdr.nodes.count;
+        const uint32_t arrays = count <= 512u ? 512u : count <= 1536u ? 1536u : 0u;
+        if (all_cached && arrays != 0u && !(force & 16u) && lds_stack_bytes + (size_t)arrays * 14u * sizeof(uint32_t) + 16 <= ctx->lds_per_block) {
+            out->kernel = arrays == 512u ? arrays512[query] : arrays1536[query];
+            lds = lds_stack_bytes + (size_t)arrays * 14u * sizeof(uint32_t) + 16;
+        }
     }
     out->list_only = sc->hdr.world_tree == RT_REF_NONE && !(force & 4u);
     if (out->list_only) { // nothing to walk per lane
@@ -1599,7 +1676,7 @@ int rt_trace_first_hit(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays
 int rt_trace_first_hit_wavefront(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays, size_t n, const double* medium_xi,
                                  rt_hit* out, uint32_t variant) try {
     if (!ctx) return RT_ERR_INVALID;
-    if (!sc || (!rays && n) || (!out && n) || n > 0x7FFFFFFFu || variant > 15u) return ctx_fail(ctx, RT_ERR_INVALID, "trace_first_hit_wavefront: bad argument");
+    if (!sc || (!rays && n) || (!out && n) || n > 0x7FFFFFFFu || variant > 31u) return ctx_fail(ctx, RT_ERR_INVALID, "trace_first_hit_wavefront: bad argument");
     if (n == 0) return RT_OK;
     for (size_t i = 0; i < n; ++i)
         if (rays[i].time < sc->hdr.valid0 || rays[i].time > sc->hdr.valid1)

@@ -134,8 +134,8 @@ def test_random_scene_graphs_on_the_gpu(gpu_ctx, seed):
         # the same rays through the renderer's traversal kernel (frames of their own, nested lists, replay trees, media
         # on boxes under instances): the same records, byte for byte
         # (4, 7: the tree kernel also where the scene has no tree and the renderer would take the list kernel; 8: the general
-        # instantiation also where the tree has only plain leaves)
-        for variant in (0, 3, 4, 7, 8):
+        # instantiation also where the tree has only plain leaves; 16: node records in LDS as records, not as arrays)
+        for variant in (0, 3, 4, 7, 8, 16):
             assert gpu_ctx.trace_first_hit(scene, rays, xi, wavefront=variant).tobytes() == lane.tobytes(), (seed, flags, variant)
         scene.close()
 
