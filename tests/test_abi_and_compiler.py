@@ -196,6 +196,31 @@ def test_a_small_reference_order_tree_becomes_lock_step_steps():
     assert all(depth[i + 1] == depth[i] + 1 for i in range(n - 1) if gates[i])
 
 
+def test_a_world_of_a_few_plain_objects_goes_onto_the_list_whole():
+    """cornell_smoke: eight objects in a plain list (five walls, the light, two media on instanced boxes). No tree: every
+    object a step at depth 1, in the world's own order; a moving sphere or builder flag 8 (a tree for the device to build)
+    keeps the tree."""
+    b, info, blob, _ = util.build_scene("cornell_smoke")
+    h = header(blob)
+    s = h["sections"]
+    assert s["nodes"][1] == 0 and h["world_tree"] == 0 and (h["world_flat"] >> 28) == 8 and h["world_flat"] == h["world_flat_any_time"]
+    entries = np.frombuffer(blob, dtype="<u4", count=s["list_entries"][1], offset=s["list_entries"][0])
+    at = h["world_flat"] & 0x03FFFFFF
+    n = int(entries[at] & 0x03FFFFFF)
+    assert entries[at] >> 28 == 11 and n == 8 and entries[at + 1 + 2 * n] == 0
+    ctrl, operand = entries[at + 1:at + 1 + 2 * n:2], entries[at + 2:at + 2 + 2 * n:2]
+    assert np.all(ctrl == 1)                                   # no box test, everything at depth 1
+    assert (operand >> 28).tolist() == [4, 4, 4, 4, 4, 4, 6, 6]   # main.rs:488-574: the walls and the light, then the two media
+    _, _, blob8, _ = util.build_scene("cornell_smoke", flags=api.FLAG_DEVICE_TREE)
+    h8 = header(blob8)
+    assert h8["sections"]["nodes"][1] >= 7 and (h8["world_tree"] >> 28) == 1
+    # the Book-1 scene has 480-odd objects: a tree, and its huge ground sphere on the list as a plain entry
+    _, _, big, _ = util.build_scene("random_scene")
+    hb = header(big)
+    eb = np.frombuffer(big, dtype="<u4", count=hb["sections"]["list_entries"][1], offset=hb["sections"]["list_entries"][0])
+    assert (hb["world_tree"] >> 28) == 1 and not np.any(eb >> 28 == 11)
+
+
 def test_cornell_replays_the_reference_order(monkeypatch):
     monkeypatch.setenv("RT_NO_LOCKSTEP_TREE", "1")            # the form a larger tree of that kind takes
     b, info, blob, _ = util.build_scene("cornell_box")
