@@ -1398,14 +1398,15 @@ void launch_shade(rt_context* ctx, const rt_scene* sc, const PassInfo& pi, const
     if (!(sc->bucket_mask >> BUCKET & 1u)) return; // no material of the scene is shaded by this kernel
     size_t a = tm.begin();
     constexpr uint32_t kChecker = 1u << RT_TEX_CHECKER, kImage = 1u << RT_TEX_IMAGE;
-    // A scene whose only computed textures are checkers (a ground of two colours) or, Lambertian over noise having a bucket of
-    // its own, images (a globe) runs the kernel without the code for the other kinds.
+    // A scene whose only computed textures are checkers (a ground of two colours) or images (a globe, emissive pictures) - for
+    // textured Lambertian also beside noise, which has a bucket of its own there - runs the kernel without the code for the
+    // other kinds.
     bool launched = false;
     if constexpr (BUCKET != RT_BUCKET_LAMBERTIAN_NOISE) {
         if (sc->tex_kinds == kChecker) {
             hipLaunchKernelGGL((k_shade<BUCKET, kChecker>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, sc->view, pi, pb, qs, it);
             launched = true;
-        } else if ((sc->tex_kinds & ~(1u << RT_TEX_NOISE)) == kImage && BUCKET == RT_BUCKET_LAMBERTIAN_TEX) {
+        } else if (sc->tex_kinds == kImage || ((sc->tex_kinds & ~(1u << RT_TEX_NOISE)) == kImage && BUCKET == RT_BUCKET_LAMBERTIAN_TEX)) {
             hipLaunchKernelGGL((k_shade<BUCKET, kImage>), dim3(grid), dim3(RT_BLOCK), 0, ctx->stream, sc->view, pi, pb, qs, it);
             launched = true;
         }
