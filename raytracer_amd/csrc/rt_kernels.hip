@@ -1380,6 +1380,9 @@ int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t f
         out->kernel = lists[sphere_media][query];
         lds = 0;
         out->stack_cap_arg = sc->steps_at; out->refill_arg = sc->n_steps; // (what k_extend_list takes in those two places)
+#ifdef RT_BOUNDS_CHECK
+        out->refill_arg = 0u; // the checked build walks the steps through the list's own code, which checks every reference
+#endif
     }
     if (lds > 65536)
         RT_HIP(hipFuncSetAttribute((const void*)out->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "LDS size of k_extend_tree");
