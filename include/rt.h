@@ -223,7 +223,9 @@ int rt_trace_first_hit(rt_context*, const rt_scene*, const rt_ray_d* rays, size_
  * bit 1 = the one with the general ConstantMedium boundary code even if every medium is bounded by a sphere,
  * bit 2 = k_extend_tree even for a scene without a tree, bit 3 = not the instantiation that leaves out the code for lists,
  * frame changes and linked instance records (which a scene whose tree has only plain leaves gets otherwise), bit 4 = the
- * node records in LDS as 64-byte records, not as arrays read by the ray's signs (which a small plain tree gets otherwise). */
+ * node records in LDS as 64-byte records, not as arrays read by the ray's signs (which a small plain tree gets otherwise),
+ * bit 5 = moving spheres keep a leaf test of their own (a plain tree over a scene where at least one primitive in eight is a
+ * moving sphere otherwise runs them through the spheres' test, one square root and division sequence for both kinds). */
 int rt_trace_first_hit_wavefront(rt_context*, const rt_scene*, const rt_ray_d* rays, size_t n, const double* medium_xi,
                                  rt_hit* out, uint32_t variant);
 

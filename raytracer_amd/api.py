@@ -202,7 +202,7 @@ class Context:
 
     def trace_first_hit(self, scene, rays, medium_xi=None, noalloc=False, wavefront=None):
         """noalloc=True: through rt_trace_first_hit_noalloc (fixed work area, limited batch, no device allocation).
-        wavefront=v (0..31): through rt_trace_first_hit_wavefront, i.e. the renderer's traversal kernel, variant v."""
+        wavefront=v (0..63): through rt_trace_first_hit_wavefront, i.e. the renderer's traversal kernel, variant v."""
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
         out = np.zeros(len(rays), dtype=HIT_DTYPE)
         xi = None

@@ -265,6 +265,26 @@ RT_HD bool rt_sphere_t(V3 center, double radius, const Ray& r, double t_min, dou
     return false;
 }
 
+// Both of the above behind one flag per lane, so that a wave whose lanes hold spheres of both kinds runs the square root and
+// the divisions once: `inclusive` chooses MovingSphere::hit's comparisons (a zero discriminant hits, the ends of the t range
+// count), else Sphere::hit's. The arithmetic of the two is the same, term for term.
+RT_HD bool rt_either_sphere_t(V3 center, double radius, bool inclusive, const Ray& r, double t_min, double t_max, double& t_out) {
+    V3 oc = r.o - center;
+    double a = v3_sqlen(r.d);
+    double half_b = v3_dot(r.d, oc);
+    double c = v3_sqlen(oc) - radius * radius;
+    double delta = half_b * half_b - a * c;
+    if (inclusive ? delta < 0.0 : !(delta > 0.0)) return false;
+    double root = sqrt(delta);
+    double t = (-half_b - root) / a;
+    if (inclusive ? (t < t_min || t > t_max) : !(t > t_min && t < t_max)) {
+        t = (-half_b + root) / a;
+        if (inclusive ? (t < t_min || t > t_max) : !(t > t_min && t < t_max)) return false;
+    }
+    t_out = t;
+    return true;
+}
+
 // MovingSphere::center (moving_sphere.rs:37-40)
 RT_HD V3 rt_msphere_center(const RtMSphere& s, double time) {
     V3 c0 = v3(s.c0[0], s.c0[1], s.c0[2]), c1 = v3(s.c1[0], s.c1[1], s.c1[2]);
@@ -587,7 +607,10 @@ RT_HD void rt_trav_descend(const Nodes& nodes, RtTrav& s, Stack& st, double t_mi
 // at most two steps (the caller has checked: no list entry, no instance record, no frame to leave ever arrives here). The
 // branches for those are left out, and a leaf's record and the steps of its chain are all asked for before any of them is
 // used (one wait instead of up to four in a row).
-template <bool AHEAD = false, class Stack, class XiFn, class RayFn>
+// MERGE_MOVING (with AHEAD): a moving sphere's centre at the ray's time is worked out first and its lane then takes the
+// spheres' test along with theirs (rt_either_sphere_t) - for scenes with many of them, where a wave at its leaves holds
+// both kinds and would run the square root and the divisions twice.
+template <bool AHEAD = false, bool MERGE_MOVING = false, class Stack, class XiFn, class RayFn>
 RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, const XiFn& xi, bool skip_media,
                          const RayFn& world_ray) {
     const uint32_t idx = RT_REF_INDEX(s.cur);
@@ -620,7 +643,8 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
         Ray moved = s.r;
         if (type == RT_REF_ILEAF) leaf = RT_ILEAF_PRIM(s.cur);
         constexpr bool ahead = AHEAD;
-        const bool sphere_ahead = ahead && RT_REF_TYPE(leaf) == RT_REF_SPHERE;
+        const bool moving_ahead = ahead && MERGE_MOVING && RT_REF_TYPE(leaf) == RT_REF_MSPHERE;
+        const bool sphere_ahead = (ahead && RT_REF_TYPE(leaf) == RT_REF_SPHERE) || moving_ahead;
         const bool box_ahead = ahead && RT_REF_TYPE(leaf) == RT_REF_BOX;
         const bool medium_ahead = ahead && RT_REF_TYPE(leaf) == RT_REF_MEDIUM && !skip_media;
         // (a sphere's four doubles or a box's six, asked for beside the chain's record and before the wave works through
@@ -628,10 +652,14 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
         RtBox rec;
         rec.p0[0] = 0.0; rec.p0[1] = 0.0; rec.p0[2] = 0.0; rec.p1[0] = 0.0; rec.p1[1] = 0.0; rec.p1[2] = 0.0;
 #ifdef RT_BOUNDS_CHECK
-        if ((sphere_ahead && !RT_IN_RANGE(sc, spheres, RT_REF_INDEX(leaf), s.cur)) || (box_ahead && !RT_IN_RANGE(sc, boxes, RT_REF_INDEX(leaf), s.cur)) ||
+        if ((moving_ahead && !RT_IN_RANGE(sc, mspheres, RT_REF_INDEX(leaf), s.cur)) || (sphere_ahead && !moving_ahead && !RT_IN_RANGE(sc, spheres, RT_REF_INDEX(leaf), s.cur)) || (box_ahead && !RT_IN_RANGE(sc, boxes, RT_REF_INDEX(leaf), s.cur)) ||
             (medium_ahead && !RT_IN_RANGE(sc, media, RT_REF_INDEX(leaf), s.cur))) { s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop(); return; }
 #endif
-        if (sphere_ahead) {
+        if (moving_ahead) { // (its centre at the ray's time - no step of a chain changes that - and the lane is one of the spheres')
+            const RtMSphere ms = sc.mspheres[RT_REF_INDEX(leaf)];
+            const V3 c = rt_msphere_center(ms, s.r.tm);
+            rec.p0[0] = c.x; rec.p0[1] = c.y; rec.p0[2] = c.z; rec.p1[0] = ms.r;
+        } else if (sphere_ahead) {
             const RtSphere sp = sc.spheres[RT_REF_INDEX(leaf)];
             rec.p0[0] = sp.cx; rec.p0[1] = sp.cy; rec.p0[2] = sp.cz; rec.p1[0] = sp.r;
         } else if (box_ahead) {
@@ -671,8 +699,10 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
         }
         if (sphere_ahead) {
             double t;
-            RT_VISIT(1u + RT_REF_SPHERE);
-            if (rt_sphere_t(v3(rec.p0[0], rec.p0[1], rec.p0[2]), rec.p1[0], moved, t_min, s.best.t, t)) { s.best.t = t; s.best.ref = leaf; s.best.aux = 0u; }
+            RT_VISIT(1u + RT_REF_TYPE(leaf));
+            const bool got = MERGE_MOVING ? rt_either_sphere_t(v3(rec.p0[0], rec.p0[1], rec.p0[2]), rec.p1[0], moving_ahead, moved, t_min, s.best.t, t)
+                                          : rt_sphere_t(v3(rec.p0[0], rec.p0[1], rec.p0[2]), rec.p1[0], moved, t_min, s.best.t, t);
+            if (got) { s.best.t = t; s.best.ref = leaf; s.best.aux = 0u; }
         } else if (box_ahead) {
             double t;
             uint32_t face = 0u;

@@ -465,7 +465,9 @@ __device__ __forceinline__ void rt_node_step_signed(const SignedNodes<ARRAYS>& a
 // one sphere-bounded medium of the short cut (rt_extend_flat<true>).
 // ARRAYS > 0: the node records in LDS as fourteen arrays of that many words (rt_node_step_signed); needs PLAIN, ALL_CACHED,
 // no exact nodes, and at most ARRAYS nodes.
-template <bool EXACT_NODES, bool SPHERE_MEDIA, bool QUERY, bool ALL_CACHED, bool PLAIN = false, int ARRAYS = 0>
+// MERGE_MOVING = true (with PLAIN): for scenes with many moving spheres, which then go through the spheres' leaf test
+// (rt_trav_visit<true, true>).
+template <bool EXACT_NODES, bool SPHERE_MEDIA, bool QUERY, bool ALL_CACHED, bool PLAIN = false, int ARRAYS = 0, bool MERGE_MOVING = false>
 __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassInfo pi, PathBufs pb, QueueSet qs, uint32_t it,
                                                                uint32_t stack_cap, uint32_t refill_min, uint32_t leaf_pct,
                                                                uint32_t n_cached, uint32_t n_exact_lds, QueryBatch qb) {
@@ -486,6 +488,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
         return xi;
     };
     // queue positions handed out in this workgroup so far: the 16 bytes behind the node records
+    static_assert(!MERGE_MOVING || PLAIN, "moving spheres join the spheres' test only in the code for plain leaves");
     static_assert(ARRAYS == 0 || (PLAIN && ALL_CACHED && !EXACT_NODES && ARRAYS % 64 == 0), "the array layout is for small plain trees");
     const size_t node_words = ARRAYS > 0 ? (size_t)14u * (size_t)ARRAYS : (size_t)n_cached * 16u;
     uint32_t& blk_taken = *(uint32_t*)(lds_tree + (size_t)stack_cap * blockDim.x / 4u + node_words / 4u);
@@ -628,11 +631,11 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             if constexpr (QUERY) {
                 QueryRay ray_of;
                 ray_of.q = qb.rays + path;
-                rt_trav_visit<PLAIN>(sc, s, st, t_min, xi_of(id, path), skip_media, ray_of);
+                rt_trav_visit<PLAIN, MERGE_MOVING>(sc, s, st, t_min, xi_of(id, path), skip_media, ray_of);
             } else {
                 SlotRay ray_of;
                 ray_of.rec = rays + path;
-                rt_trav_visit<PLAIN>(sc, s, st, t_min, xi_of(id, path), skip_media, ray_of);
+                rt_trav_visit<PLAIN, MERGE_MOVING>(sc, s, st, t_min, xi_of(id, path), skip_media, ray_of);
             }
         }
         if (active && s.cur == RT_REF_NONE) { // finished: publish the closest hit
@@ -1333,7 +1336,7 @@ struct ExtendLaunch {
 // `force`: bit 0 = the instantiation with exact f64 box tests even if the scene has no node that needs them, bit 1 = the
 // one with the general medium-boundary code even if every medium is bounded by a sphere (both are valid for any scene),
 // bit 2 = the tree kernel even for a scene without a tree, bit 3 = not the instantiation for trees with plain leaves, bit 4 = not the
-// array layout of the node records in LDS.
+// array layout of the node records in LDS, bit 5 = moving spheres keep a leaf test of their own however many there are.
 int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t force, ExtendLaunch* out) {
     const uint32_t stack_cap = sc->hdr.stack_need;
     // Persistent waves, one workgroup per CU: its LDS holds the traversal stacks and, in what is left, the first
@@ -1361,16 +1364,22 @@ int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t f
     // a tree with plain leaves: the instantiation without the code for lists and frame changes (not for a scene without a
     // tree: its lock-step list may hold a small tree's steps, which that instantiation's list walk leaves out)
     if (sc->plain_leaves && !exact_nodes && sphere_media && sc->hdr.world_tree != RT_REF_NONE && !(force & 8u)) {
-        static const ExtendKernel plain_tree[2][2] = {{k_extend_tree<false, true, false, false, true>, k_extend_tree<false, true, false, true, true>},
-                                                       {k_extend_tree<false, true, true, false, true>, k_extend_tree<false, true, true, true, true>}};
-        out->kernel = plain_tree[query][all_cached];
+        // (many moving spheres - one primitive in eight or more: the instantiations whose sphere test takes them along)
+        const size_t prims = sc->hdr.spheres.count + sc->hdr.mspheres.count + sc->hdr.rects.count + sc->hdr.boxes.count;
+        const bool mm = sc->hdr.mspheres.count * 8u >= prims && sc->hdr.mspheres.count != 0u && !(force & 32u);
+#define RT_PLAIN_ROW(Q, M) {k_extend_tree<false, true, Q, false, true, 0, M>, k_extend_tree<false, true, Q, true, true, 0, M>}
+        static const ExtendKernel plain_tree[2][2][2] = {{RT_PLAIN_ROW(false, false), RT_PLAIN_ROW(true, false)}, {RT_PLAIN_ROW(false, true), RT_PLAIN_ROW(true, true)}};
+#undef RT_PLAIN_ROW
+        out->kernel = plain_tree[mm][query][all_cached];
         // every node in LDS and few enough of them: the records as fourteen arrays (rt_node_step_signed), if that fits too
-        static const ExtendKernel arrays512[2] = {k_extend_tree<false, true, false, true, true, 512>, k_extend_tree<false, true, true, true, true, 512>};
-        static const ExtendKernel arrays1536[2] = {k_extend_tree<false, true, false, true, true, 1536>, k_extend_tree<false, true, true, true, true, 1536>};
+#define RT_ARRAYS_ROW(N, M) {k_extend_tree<false, true, false, true, true, N, M>, k_extend_tree<false, true, true, true, true, N, M>}
+        static const ExtendKernel arrays512[2][2] = {RT_ARRAYS_ROW(512, false), RT_ARRAYS_ROW(512, true)};
+        static const ExtendKernel arrays1536[2][2] = {RT_ARRAYS_ROW(1536, false), RT_ARRAYS_ROW(1536, true)};
+#undef RT_ARRAYS_ROW
         const size_t count = sc->hdr.nodes.count;
         const uint32_t arrays = count <= 512u ? 512u : count <= 1536u ? 1536u : 0u;
         if (all_cached && arrays != 0u && !(force & 16u) && lds_stack_bytes + (size_t)arrays * 14u * sizeof(uint32_t) + 16 <= ctx->lds_per_block) {
-            out->kernel = arrays == 512u ? arrays512[query] : arrays1536[query];
+            out->kernel = arrays == 512u ? arrays512[mm][query] : arrays1536[mm][query];
             lds = lds_stack_bytes + (size_t)arrays * 14u * sizeof(uint32_t) + 16;
         }
     }
@@ -1680,7 +1689,7 @@ int rt_trace_first_hit(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays
 int rt_trace_first_hit_wavefront(rt_context* ctx, const rt_scene* sc, const rt_ray_d* rays, size_t n, const double* medium_xi,
                                  rt_hit* out, uint32_t variant) try {
     if (!ctx) return RT_ERR_INVALID;
-    if (!sc || (!rays && n) || (!out && n) || n > 0x7FFFFFFFu || variant > 31u) return ctx_fail(ctx, RT_ERR_INVALID, "trace_first_hit_wavefront: bad argument");
+    if (!sc || (!rays && n) || (!out && n) || n > 0x7FFFFFFFu || variant > 63u) return ctx_fail(ctx, RT_ERR_INVALID, "trace_first_hit_wavefront: bad argument");
     if (n == 0) return RT_OK;
     for (size_t i = 0; i < n; ++i)
         if (rays[i].time < sc->hdr.valid0 || rays[i].time > sc->hdr.valid1)

@@ -80,7 +80,7 @@ def test_wavefront_first_hit_edge_cases(gpu_ctx):
         xi = np.tile(np.array([[0.3, 0.7]]), (n, 1))
         assert gpu_ctx.trace_first_hit(scene, r, xi, wavefront=3).tobytes() == gpu_ctx.trace_first_hit(scene, r, xi).tobytes()
     with pytest.raises(api.RtError):
-        gpu_ctx.trace_first_hit(scene, rays, None, wavefront=32)
+        gpu_ctx.trace_first_hit(scene, rays, None, wavefront=64)
     scene.close()
 
 

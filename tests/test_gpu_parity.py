@@ -135,7 +135,7 @@ def test_random_scene_graphs_on_the_gpu(gpu_ctx, seed):
         # on boxes under instances): the same records, byte for byte
         # (4, 7: the tree kernel also where the scene has no tree and the renderer would take the list kernel; 8: the general
         # instantiation also where the tree has only plain leaves; 16: node records in LDS as records, not as arrays)
-        for variant in (0, 3, 4, 7, 8, 16):
+        for variant in (0, 3, 4, 7, 8, 16, 32):
             assert gpu_ctx.trace_first_hit(scene, rays, xi, wavefront=variant).tobytes() == lane.tobytes(), (seed, flags, variant)
         scene.close()
 
@@ -229,6 +229,36 @@ def test_shutter_outside_the_interval_of_a_bvh_over_moving_spheres(gpu_ctx):
     got = gpu_ctx.render(scene, cam, p, 2)
     want, _ = ck.OracleScene(desc, share_bvh_axes=True).render(cam, p, 2)
     assert float((util.rel_err(got, want) > 1e-9).mean()) <= 0.002
+    scene.close()
+
+
+def test_a_range_that_ends_on_the_hit_keeps_a_moving_sphere_and_drops_a_sphere(gpu_ctx):
+    """MovingSphere::hit takes the ends of its t range (moving_sphere.rs:57-62), Sphere::hit does not (sphere.rs:50-59).
+    The traversal kernel runs both kinds through one test in a scene with many moving spheres (variant bit 5 = apart):
+    rays whose range ends to the bit on their first hit tell the two comparisons apart."""
+    _, info, blob, desc = util.build_scene("random_scene")
+    osc = ck.OracleScene(desc, share_bvh_axes=True)
+    scene = gpu_ctx.upload(blob)
+    p = api.params_from_info(info, width=240, height=160, seed=util.RENDER_SEED)
+    cam = gpu_ctx.generate_rays(info.camera, p, 0)
+    first = gpu_ctx.trace_first_hit(scene, cam)
+    hit = first["prim_id"] != MISS
+    ends = cam[hit].copy()
+    ends["tmax"] = first["t"][hit]
+    starts = cam[hit].copy()
+    starts["tmin"] = first["t"][hit]
+    kept = 0
+    for rays in (cam, ends, starts):
+        lane = gpu_ctx.trace_first_hit(scene, rays)
+        want = osc.trace_first_hit(rays, None)
+        rep = util.first_hit_report(lane, want)
+        assert rep["prim_match"] >= 0.9999 and rep["t_rel_max"] <= 1e-5, rep
+        for variant in (0, 32):
+            assert gpu_ctx.trace_first_hit(scene, rays, wavefront=variant).tobytes() == lane.tobytes(), variant
+        if rays is ends:
+            again = (lane["prim_id"] == first["prim_id"][hit]) & (lane["t"] == first["t"][hit])
+            kept = int(again.sum())
+            assert 0 < kept < len(rays)                             # the moving spheres' rays hit again, the spheres' do not
     scene.close()
 
 

@@ -39,7 +39,7 @@ for seed in range(lo, hi):
         n += 1
         ok = rep["prim_match"] >= 0.9995 and rep["t_rel_max"] <= 1e-5 and rep["t_bit_equal"] >= 0.95
         # the renderer's closest-hit kernels (the one the scene gets, and the general tree kernel): the same records
-        for variant in (0, 12, 16):
+        for variant in (0, 12, 16, 32):
             if ctx.trace_first_hit(scene, rays, xi, wavefront=variant).tobytes() != lane.tobytes():
                 ok = False
                 print("KERNELS DISAGREE", seed, flags, variant, flush=True)
