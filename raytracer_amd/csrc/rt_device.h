@@ -562,6 +562,9 @@ RT_HD uint32_t rt_stack_node_step(Stack& st, bool both, bool any, uint32_t go, u
     if (both) st.push(keep);
     return any ? go : (st.empty() ? (uint32_t)RT_REF_NONE : st.pop());
 }
+// ... and pop_or_none(), where the stack can do "the top entry, or RT_REF_NONE from an empty stack" without asking which.
+template <class Stack> RT_HD auto rt_stack_pop_or_none(Stack& st, int) -> decltype(st.pop_or_none()) { return st.pop_or_none(); }
+template <class Stack> RT_HD uint32_t rt_stack_pop_or_none(Stack& st, long) { return st.empty() ? (uint32_t)RT_REF_NONE : st.pop(); }
 // EXACT_NODES = false: for scenes without a node flagged RT_NODE_EXACT (the flag is then not looked at).
 template <bool EXACT_NODES = true, class Stack, class Nodes>
 RT_HD void rt_trav_node_step(const Nodes& nodes, RtTrav& s, Stack& st, double t_min) {
@@ -594,8 +597,8 @@ RT_HD void rt_trav_node_step(const Nodes& nodes, RtTrav& s, Stack& st, double t_
     h1 = h1 && n.c1 != RT_REF_NONE; // (an absent child has the empty box, which a ray without direction would still "hit")
     // both boxes hit: on with the nearer child, the other is kept for later; one: on with it; none: the next kept one
     const bool both = h0 && h1;
-    const uint32_t go = both ? (swap ? n.c1 : n.c0) : (h0 ? n.c0 : n.c1);
-    s.cur = rt_stack_node_step(st, both, h0 || h1, go, swap ? n.c0 : n.c1, under, 0);
+    const bool first0 = h0 & (!h1 | !swap); // on with child 0: the nearer of two, or the only one (and the other one is what is kept of two)
+    s.cur = rt_stack_node_step(st, both, h0 || h1, first0 ? n.c0 : n.c1, first0 ? n.c1 : n.c0, under, 0);
 }
 template <class Stack, class Nodes>
 RT_HD void rt_trav_descend(const Nodes& nodes, RtTrav& s, Stack& st, double t_min) {
@@ -622,7 +625,7 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
         else if (type == RT_REF_POP || type == RT_REF_INST) ok = RT_IN_RANGE(sc, insts, idx, s.cur);
         else if (type == RT_REF_ILEAF) ok = RT_IN_RANGE(sc, chains, RT_ILEAF_CHAIN(s.cur), s.cur);
         else if (type > RT_REF_ILEAF || type == RT_REF_NODE || type == RT_REF_NONE) ok = rt_in_range("reference type at a leaf", type, 0u, s.cur);
-        if (!ok) { s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop(); return; }
+        if (!ok) { s.cur = rt_stack_pop_or_none(st, 0); return; }
     }
 #endif
     if (!AHEAD && type == RT_REF_LIST) { // HittableList: entries in order (hittable_list.rs:45-51)
@@ -653,7 +656,7 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
         rec.p0[0] = 0.0; rec.p0[1] = 0.0; rec.p0[2] = 0.0; rec.p1[0] = 0.0; rec.p1[1] = 0.0; rec.p1[2] = 0.0;
 #ifdef RT_BOUNDS_CHECK
         if ((moving_ahead && !RT_IN_RANGE(sc, mspheres, RT_REF_INDEX(leaf), s.cur)) || (sphere_ahead && !moving_ahead && !RT_IN_RANGE(sc, spheres, RT_REF_INDEX(leaf), s.cur)) || (box_ahead && !RT_IN_RANGE(sc, boxes, RT_REF_INDEX(leaf), s.cur)) ||
-            (medium_ahead && !RT_IN_RANGE(sc, media, RT_REF_INDEX(leaf), s.cur))) { s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop(); return; }
+            (medium_ahead && !RT_IN_RANGE(sc, media, RT_REF_INDEX(leaf), s.cur))) { s.cur = rt_stack_pop_or_none(st, 0); return; }
 #endif
         if (moving_ahead) { // (its centre at the ray's time - no step of a chain changes that - and the lane is one of the spheres')
             const RtMSphere ms = sc.mspheres[RT_REF_INDEX(leaf)];
@@ -720,7 +723,7 @@ RT_HD void rt_trav_visit(const DScene& sc, RtTrav& s, Stack& st, double t_min, c
             rt_test_leaf(sc, leaf, moved, t_min, s.best, xi, skip_media);
         }
     }
-    s.cur = st.empty() ? (uint32_t)RT_REF_NONE : st.pop();
+    s.cur = rt_stack_pop_or_none(st, 0);
 }
 
 // Everything below `root`, per lane, starting from an empty stack. `r` is the ray of root's frame.

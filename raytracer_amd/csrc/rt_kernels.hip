@@ -102,35 +102,45 @@ __device__ inline LiveSet live_set(const uint32_t* ctr, size_t cap) {
 
 // The newest entry is held in a register (`tos`), the older ones in LDS: a pop hands out the register at once and only
 // then asks the LDS for the entry below, which nothing needs before the next pop or push - so the wave does not sit out an
-// LDS round trip in front of the node fetch that follows every pop. Entry j (counted from the bottom) of the ones in LDS is
-// at base[(j + 1) * stride]; base[0] takes the meaningless register contents that the first push writes out.
+// LDS round trip in front of the node fetch that follows every pop. Everything is kept as LDS byte addresses (a push or
+// pop is an add, the slot to write is `top` itself), and two things hold throughout: `tos` is RT_REF_NONE while nothing
+// is held, and so is the word at `bottom` (the first push writes the empty stack's `tos` there) - so "pop, or
+// RT_REF_NONE from an empty stack" needs no look at whether it is empty: it hands out `tos` and steps back to
+// max(top - stride, bottom). Entry j (counted from the bottom) of the ones in LDS is at bottom + (j + 1) * stride.
 struct LdsStack {
-    uint32_t* base; // this lane's column, stride = threads per block (conflict-free)
-    uint32_t top, lim, stride; // top = entries held * stride (an offset: a push or pop is an add, not a multiply); lim = capacity * stride
+    typedef __attribute__((address_space(3))) uint32_t* Word;
+    uint32_t bottom, top, lim, stride; // this lane's column (stride = 4 * threads per block: conflict-free); the slot the next push writes; the column's end
     uint32_t tos;
     uint32_t* error_flag;
-    __device__ void init(uint32_t* column, uint32_t cap, uint32_t stride_, uint32_t* flag) { base = column; top = 0u; tos = 0u; lim = cap * stride_; stride = stride_; error_flag = flag; }
-    __device__ void clear() { top = 0u; }
+    static __device__ Word at(uint32_t a) { return (Word)(uintptr_t)a; }
+    __device__ void init(uint32_t* column, uint32_t cap, uint32_t threads, uint32_t* flag) {
+        bottom = (uint32_t)(uintptr_t)(Word)column;
+        top = bottom; tos = RT_REF_NONE; stride = 4u * threads; lim = bottom + cap * stride; error_flag = flag;
+        *at(bottom) = RT_REF_NONE;
+    }
+    __device__ void clear() { top = bottom; tos = RT_REF_NONE; }
     __device__ void push(uint32_t v) {
-        if (top < lim) { base[top] = tos; tos = v; top += stride; }
+        if (top < lim) { *at(top) = tos; tos = v; top += stride; }
         else if (error_flag) atomicOr(error_flag, 1u);
     }
-    __device__ uint32_t pop() { const uint32_t v = tos; top -= stride; tos = base[top]; return v; }
+    __device__ uint32_t below() const { return (uint32_t)max((int)(top - stride), (int)bottom); }
+    __device__ uint32_t pop() { const uint32_t v = tos; top -= stride; tos = *at(top); return v; }
+    __device__ uint32_t pop_or_none() { const uint32_t v = tos; top = below(); tos = *at(top); return v; }
     // What a pop would uncover, asked for before it is known whether one follows (rt_trav_node_step asks together with its
-    // node record, so that one wait covers both). Nothing held, or one entry: the unused word at the bottom.
-    __device__ uint32_t prefetch() const { return base[max((int)(top - stride), 0)]; }
+    // node record, so that one wait covers both). Nothing held, or one entry: the RT_REF_NONE at the bottom.
+    __device__ uint32_t prefetch() const { return *at(below()); }
     // The stack's part of a node step, without branches but for the store: both boxes hit - `keep` is pushed and the lane
     // goes on with `go`; one box - on with `go`; none - the top entry, or RT_REF_NONE from an empty stack.
     __device__ uint32_t node_step(bool both, bool any, uint32_t go, uint32_t keep, uint32_t under) {
-        const bool pushing = both && top < lim, popping = !any && top != 0u;
-        if (pushing) base[top] = tos;
+        const bool pushing = both && top < lim;
+        if (pushing) *at(top) = tos;
         else if (both && error_flag) atomicOr(error_flag, 1u);
-        const uint32_t cur = any ? go : (popping ? tos : (uint32_t)RT_REF_NONE);
-        tos = pushing ? keep : (popping ? under : tos);
-        top = pushing ? top + stride : (popping ? top - stride : top);
+        const uint32_t cur = any ? go : tos;
+        tos = pushing ? keep : (any ? tos : under);
+        top = pushing ? top + stride : (any ? top : below());
         return cur;
     }
-    __device__ bool empty() const { return top == 0u; }
+    __device__ bool empty() const { return top == bottom; }
 };
 
 // The first n_cached node records live in LDS, the rest in global memory. A lane fetches a 64-byte record with four
@@ -430,10 +440,16 @@ struct SignedNodes {
         }
     }
 };
+// In this layout a node is not named by RT_MAKE_REF(RT_REF_NODE, i) but by RT_ARRAYS_NODE | 4 i (the children are rewritten
+// when the arrays are filled, the root when a lane takes a ray): "at a node" is then one unsigned comparison, and with the
+// array addresses a lane holds lowered by RT_ARRAYS_NODE the name itself is what is added to them (no shift, no mask -
+// three vector instructions less per step). References to anything else keep their form; none has all four type bits set.
+#define RT_ARRAYS_NODE 0xF0000000u
+__device__ __forceinline__ uint32_t rt_arrays_name(uint32_t ref) { return RT_REF_TYPE(ref) == RT_REF_NODE ? (RT_ARRAYS_NODE | (RT_REF_INDEX(ref) << 2)) : ref; }
 template <int ARRAYS>
 __device__ __forceinline__ void rt_node_step_signed(const SignedNodes<ARRAYS>& at, uint32_t child_base, RtTrav& s, LdsStack& st, double t_min) {
     const uint32_t under = st.prefetch();
-    const uint32_t i4 = RT_REF_INDEX(s.cur) << 2;
+    const uint32_t i4 = s.cur; // (RT_ARRAYS_NODE | 4 i against addresses lowered by RT_ARRAYS_NODE: the sum wraps to the word's address)
     constexpr uint32_t kBox1 = 6u * (uint32_t)ARRAYS;
     const LdsF32 nx = (LdsF32)(uintptr_t)(at.near_at[0] + i4), ny = (LdsF32)(uintptr_t)(at.near_at[1] + i4), nz = (LdsF32)(uintptr_t)(at.near_at[2] + i4);
     const LdsF32 fx = (LdsF32)(uintptr_t)(at.far_at[0] + i4), fy = (LdsF32)(uintptr_t)(at.far_at[1] + i4), fz = (LdsF32)(uintptr_t)(at.far_at[2] + i4);
@@ -450,8 +466,8 @@ __device__ __forceinline__ void rt_node_step_signed(const SignedNodes<ARRAYS>& a
     const bool swap = e1 < e0;
     h1 = h1 && c1 != RT_REF_NONE;
     const bool both = h0 && h1;
-    const uint32_t go = both ? (swap ? c1 : c0) : (h0 ? c0 : c1);
-    s.cur = st.node_step(both, h0 || h1, go, swap ? c0 : c1, under);
+    const bool first0 = h0 & (!h1 | !swap); // on with child 0: the nearer of two, or the only one (and the other one is what is kept of two)
+    s.cur = st.node_step(both, h0 || h1, first0 ? c0 : c1, first0 ? c1 : c0, under);
 }
 
 // EXACT_NODES = false: the scene has no node whose box tests must reproduce the reference's f64 arithmetic.
@@ -503,7 +519,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             uint32_t* arrays = (uint32_t*)cache;
             const uint32_t* words = (const uint32_t*)sc.nodes;
             for (uint32_t w = threadIdx.x; w < n_cached * 16u; w += blockDim.x)
-                if ((w & 15u) < 14u) arrays[(w & 15u) * (uint32_t)ARRAYS + (w >> 4)] = words[w];
+                if ((w & 15u) < 14u) arrays[(w & 15u) * (uint32_t)ARRAYS + (w >> 4)] = (w & 15u) >= 12u ? rt_arrays_name(words[w]) : words[w];
         } else {
             for (uint32_t i = threadIdx.x; i < n_cached * 4u; i += blockDim.x) cache[CachedNodes<ALL_CACHED>::place(i >> 2, i & 3u, n_cached)] = src[i];
         }
@@ -542,6 +558,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
         const unsigned long long piece = (unsigned long long)(v >> shift) * gridDim.x + blockIdx.x;
         return (piece << shift) + (v & ((1u << shift) - 1u));
     };
+    auto is_node = [](uint32_t ref) -> bool { return ARRAYS > 0 ? ref >= RT_ARRAYS_NODE : RT_REF_TYPE(ref) == RT_REF_NODE; };
 #ifdef RT_PHASE_STATS
     unsigned long long ph[48] = {};
 #endif
@@ -575,8 +592,8 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
                     held.r = &s.r;
                     rt_extend_flat<PLAIN>(sc, held, t_min, s.best, xi_of(id, path), skip_media);
                     if (PLAIN || sc.world_tree != RT_REF_NONE) s.slab = rt_slab_of<EXACT_NODES>(s.r, sc.node_extent); // (a scene without a tree: none of the PLAIN instantiations is its kernel)
-                    if constexpr (ARRAYS > 0) picked.take(arrays_at, s.slab);
-                    s.cur = sc.world_tree;
+                    if constexpr (ARRAYS > 0) picked.take(arrays_at - RT_ARRAYS_NODE, s.slab);
+                    s.cur = ARRAYS > 0 ? rt_arrays_name(sc.world_tree) : sc.world_tree;
                     st.clear();
                     active = true;
                 }
@@ -597,15 +614,15 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
         // is the ballot, and the lanes that wait are counted from it by scalar instructions alone.)
 #pragma unroll 1
         for (;;) {
-            const bool at_node = RT_REF_TYPE(s.cur) == RT_REF_NODE;
+            const bool at_node = is_node(s.cur);
             const unsigned long long m_node = rt_ballot(at_node);
             if (m_node == 0ull) break;
             if (n_active - (uint32_t)__popcll(m_node) >= leaf_now) break;
             RT_PHASE_ADD(3, 1); RT_PHASE_ADD(4, __popcll(m_node));
             if constexpr (ARRAYS > 0) {
-                const uint32_t kids_at = arrays_at + 4u * 12u * (uint32_t)ARRAYS;
+                const uint32_t kids_at = arrays_at - RT_ARRAYS_NODE + 4u * 12u * (uint32_t)ARRAYS;
                 if (at_node) rt_node_step_signed<ARRAYS>(picked, kids_at, s, st, t_min);
-                if (RT_REF_TYPE(s.cur) == RT_REF_NODE) rt_node_step_signed<ARRAYS>(picked, kids_at, s, st, t_min);
+                if (is_node(s.cur)) rt_node_step_signed<ARRAYS>(picked, kids_at, s, st, t_min);
             } else {
                 if (at_node) rt_trav_node_step<EXACT_NODES>(nodes, s, st, t_min);
                 // a second step before the next look at the wave: the two ballots above cost a sixth of a step (-3.6 % kernel
@@ -618,7 +635,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
         // ---- one non-node reference for every lane that holds one ----
 #ifdef RT_PHASE_STATS
         {
-            const bool v = active && s.cur != RT_REF_NONE && RT_REF_TYPE(s.cur) != RT_REF_NODE;
+            const bool v = active && s.cur != RT_REF_NONE && !is_node(s.cur);
             const unsigned long long any = rt_ballot(v);
             if (any) { ph[5] += 1; ph[6] += __popcll(any); }
             for (uint32_t ty = 0; ty < 16u; ++ty) {
@@ -627,7 +644,7 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
             }
         }
 #endif
-        if (active && s.cur != RT_REF_NONE && RT_REF_TYPE(s.cur) != RT_REF_NODE) {
+        if (active && s.cur != RT_REF_NONE && !is_node(s.cur)) {
             if constexpr (QUERY) {
                 QueryRay ray_of;
                 ray_of.q = qb.rays + path;
