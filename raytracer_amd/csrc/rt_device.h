@@ -162,19 +162,38 @@ struct RtSlab {
     float ix, iy, iz, cnx, cny, cnz, cfx, cfy, cfz;
 };
 // `extent`: largest |coordinate| of any box the ray will be tested against.
-// EXACT = false: for a traversal that never runs the f64 test (no RT_NODE_EXACT node in the scene): the reciprocals are
-// then only wanted to f32, and an f32 division (a tenth of the three f64 divisions' cost) gives them. The bound below
-// holds for it as well: i is then off by 2^-23 |1/d| instead of 2^-24, the product b i by as much more.
+// EXACT = false: for a traversal that never runs the f64 test (no RT_NODE_EXACT node in the scene): everything is then only
+// wanted to f32 and is worked out in f32 - the reciprocal as the hardware's estimate (one instruction; off by 2^-23 |1/d|
+// at most, and as much as 2^-24 more for d's own rounding), c as the product of the rounded origin with it. Against the
+// bound below that doubles the share of i and adds 2^-24 |c| twice over: still under a quarter of the margin. `inv` is
+// not set.
+RT_HD float rt_rcp_estimate(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
 template <bool EXACT = true>
 RT_HD RtSlab rt_slab_of(const Ray& r, double extent) {
     RtSlab s;
-    if (EXACT) {
-        s.inv = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
-        s.ix = (float)s.inv.x; s.iy = (float)s.inv.y; s.iz = (float)s.inv.z;
-    } else {
-        s.ix = 1.0f / (float)r.d.x; s.iy = 1.0f / (float)r.d.y; s.iz = 1.0f / (float)r.d.z;
-        s.inv = v3((double)s.ix, (double)s.iy, (double)s.iz);
+    if (!EXACT) {
+        s.ix = rt_rcp_estimate((float)r.d.x); s.iy = rt_rcp_estimate((float)r.d.y); s.iz = rt_rcp_estimate((float)r.d.z);
+        s.inv = v3(0.0, 0.0, 0.0);
+        // (the sign of 1/d, not of d: a component of -0.0 has the reciprocal -inf, and the near side is then the upper bound)
+        s.nx = s.ix < 0.0f; s.ny = s.iy < 0.0f; s.nz = s.iz < 0.0f;
+        const float e = (float)extent;
+        const float cx = (float)r.o.x * s.ix, cy = (float)r.o.y * s.iy, cz = (float)r.o.z * s.iz;
+        const float mx = 0x1p-20f * (e * __builtin_fabsf(s.ix) + __builtin_fabsf(cx));
+        const float my = 0x1p-20f * (e * __builtin_fabsf(s.iy) + __builtin_fabsf(cy));
+        const float mz = 0x1p-20f * (e * __builtin_fabsf(s.iz) + __builtin_fabsf(cz));
+        s.cnx = cx + mx; s.cfx = cx - mx;
+        s.cny = cy + my; s.cfy = cy - my;
+        s.cnz = cz + mz; s.cfz = cz - mz;
+        return s;
     }
+    s.inv = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    s.ix = (float)s.inv.x; s.iy = (float)s.inv.y; s.iz = (float)s.inv.z;
     // (the sign of 1/d, not of d: a component of -0.0 has the reciprocal -inf, and the near side is then the upper bound)
     s.nx = s.inv.x < 0.0; s.ny = s.inv.y < 0.0; s.nz = s.inv.z < 0.0;
     // f32 evaluation of (b - o) / d as fma(b, i, -c) with i = f32(1/d), c = f32(o/d): the result is off by at most
