@@ -450,6 +450,9 @@ template <int ARRAYS>
 __device__ __forceinline__ void rt_node_step_signed(const SignedNodes<ARRAYS>& at, uint32_t child_base, RtTrav& s, LdsStack& st, double t_min) {
     const uint32_t under = st.prefetch();
     const uint32_t i4 = s.cur; // (RT_ARRAYS_NODE | 4 i against addresses lowered by RT_ARRAYS_NODE: the sum wraps to the word's address)
+#ifdef RT_BOUNDS_CHECK
+    if (!rt_in_range("nodes (array layout)", (s.cur - RT_ARRAYS_NODE) >> 2, (uint32_t)ARRAYS, s.cur) || ((s.cur & 3u) != 0u)) { s.cur = RT_REF_NONE; return; }
+#endif
     constexpr uint32_t kBox1 = 6u * (uint32_t)ARRAYS;
     const LdsF32 nx = (LdsF32)(uintptr_t)(at.near_at[0] + i4), ny = (LdsF32)(uintptr_t)(at.near_at[1] + i4), nz = (LdsF32)(uintptr_t)(at.near_at[2] + i4);
     const LdsF32 fx = (LdsF32)(uintptr_t)(at.far_at[0] + i4), fy = (LdsF32)(uintptr_t)(at.far_at[1] + i4), fz = (LdsF32)(uintptr_t)(at.far_at[2] + i4);
