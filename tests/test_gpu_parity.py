@@ -429,6 +429,27 @@ def test_upload_rejects_bad_blobs(gpu_ctx):
         with pytest.raises(RtError):
             gpu_ctx.upload(bytes(bad))
     gpu_ctx.upload(blob).close()
+    # a tree with a node that is its own descendant (any walk of it would never end), and one whose header asks for less stack
+    # than its tree needs: the first is refused, the second renders with the kernel that checks its stack - and says so
+    _, info, blob, _ = util.build_scene("random_scene")
+    h = __import__("test_abi_and_compiler").header(blob)
+    off, count = h["sections"]["nodes"]
+    nodes = np.frombuffer(blob, dtype="<u4", count=count * 16, offset=off).reshape(count, 16)
+    inner = next(i for i in range(count) if nodes[i, 12] >> 28 == 1 and nodes[nodes[i, 12] & 0x03FFFFFF, 12] >> 28 == 1)
+    child = int(nodes[inner, 12] & 0x03FFFFFF)
+    bad = bytearray(blob)
+    bad[off + 64 * child + 48:off + 64 * child + 52] = int((1 << 28) | inner).to_bytes(4, "little")   # the child's first child: its parent
+    with pytest.raises(RtError):
+        gpu_ctx.upload(bytes(bad))
+    short = bytearray(blob)
+    assert int.from_bytes(blob[32:36], "little") == h["stack_need"] > 2
+    short[32:36] = int(2).to_bytes(4, "little")
+    scene = gpu_ctx.upload(bytes(short))
+    p = api.params_from_info(info, width=64, height=48, seed=util.RENDER_SEED)
+    with pytest.raises(RtError) as e:
+        gpu_ctx.render(scene, info.camera, p, 2)
+    assert e.value.code == -2 and "stack" in str(e.value)
+    scene.close()
 
 
 def test_empty_worlds_on_the_gpu(gpu_ctx):
