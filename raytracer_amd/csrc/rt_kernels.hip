@@ -452,7 +452,7 @@ struct SignedNodes {
 __device__ __forceinline__ uint32_t rt_arrays_name(uint32_t ref) { return RT_REF_TYPE(ref) == RT_REF_NODE ? (RT_ARRAYS_NODE | (RT_REF_INDEX(ref) << 2)) : ref; }
 template <int ARRAYS>
 __device__ __forceinline__ void rt_node_step_signed(const SignedNodes<ARRAYS>& at, uint32_t child_base, RtTrav& s, LdsStack& st, double t_min) {
-    const uint32_t under = st.prefetch();
+    uint32_t under = st.prefetch();
     const uint32_t i4 = s.cur; // (RT_ARRAYS_NODE | 4 i against addresses lowered by RT_ARRAYS_NODE: the sum wraps to the word's address)
 #ifdef RT_BOUNDS_CHECK
     if (!rt_in_range("nodes (array layout)", (s.cur - RT_ARRAYS_NODE) >> 2, (uint32_t)ARRAYS, s.cur) || ((s.cur & 3u) != 0u)) { s.cur = RT_REF_NONE; return; }
@@ -474,6 +474,7 @@ __device__ __forceinline__ void rt_node_step_signed(const SignedNodes<ARRAYS>& a
     h1 = h1 && c1 != RT_REF_NONE;
     const bool both = h0 && h1;
     const bool first0 = h0 & (!h1 | !swap); // on with child 0: the nearer of two, or the only one (and the other one is what is kept of two)
+    asm volatile("" : "+v"(under)); // (keeps the read of the entry below the top where it was asked for, in front of the box arithmetic: left alone the compiler moves it into the branch that pops, and the wave then waits out the LDS round trip there)
     s.cur = st.node_step<false>(both, h0 || h1, first0 ? c0 : c1, first0 ? c1 : c0, under); // (this layout is only chosen for trees whose stack need has been verified)
 }
 
