@@ -573,10 +573,11 @@ struct GlobalNodes {
 // pops - and node_step(), which ends the step with it: where a stack read has a latency worth hiding behind the node fetch.
 template <class Stack> RT_HD auto rt_stack_prefetch(const Stack& st, int) -> decltype(st.prefetch()) { return st.prefetch(); }
 template <class Stack> RT_HD uint32_t rt_stack_prefetch(const Stack&, long) { return 0u; }
-template <class Stack>
+// (ROOM_CHECKED = false: the caller knows the stack cannot overflow; a stack with a node_step of its own may then leave its check out)
+template <bool ROOM_CHECKED, class Stack>
 RT_HD auto rt_stack_node_step(Stack& st, bool both, bool any, uint32_t go, uint32_t keep, uint32_t under, int)
-    -> decltype(st.node_step(both, any, go, keep, under)) { return st.node_step(both, any, go, keep, under); }
-template <class Stack>
+    -> decltype(st.template node_step<ROOM_CHECKED>(both, any, go, keep, under)) { return st.template node_step<ROOM_CHECKED>(both, any, go, keep, under); }
+template <bool ROOM_CHECKED, class Stack>
 RT_HD uint32_t rt_stack_node_step(Stack& st, bool both, bool any, uint32_t go, uint32_t keep, uint32_t, long) {
     if (both) st.push(keep);
     return any ? go : (st.empty() ? (uint32_t)RT_REF_NONE : st.pop());
@@ -585,7 +586,7 @@ RT_HD uint32_t rt_stack_node_step(Stack& st, bool both, bool any, uint32_t go, u
 template <class Stack> RT_HD auto rt_stack_pop_or_none(Stack& st, int) -> decltype(st.pop_or_none()) { return st.pop_or_none(); }
 template <class Stack> RT_HD uint32_t rt_stack_pop_or_none(Stack& st, long) { return st.empty() ? (uint32_t)RT_REF_NONE : st.pop(); }
 // EXACT_NODES = false: for scenes without a node flagged RT_NODE_EXACT (the flag is then not looked at).
-template <bool EXACT_NODES = true, class Stack, class Nodes>
+template <bool EXACT_NODES = true, bool ROOM_CHECKED = true, class Stack, class Nodes>
 RT_HD void rt_trav_node_step(const Nodes& nodes, RtTrav& s, Stack& st, double t_min) {
     const uint32_t under = rt_stack_prefetch(st, 0);
 #ifdef RT_BOUNDS_CHECK
@@ -617,7 +618,7 @@ RT_HD void rt_trav_node_step(const Nodes& nodes, RtTrav& s, Stack& st, double t_
     // both boxes hit: on with the nearer child, the other is kept for later; one: on with it; none: the next kept one
     const bool both = h0 && h1;
     const bool first0 = h0 & (!h1 | !swap); // on with child 0: the nearer of two, or the only one (and the other one is what is kept of two)
-    s.cur = rt_stack_node_step(st, both, h0 || h1, first0 ? n.c0 : n.c1, first0 ? n.c1 : n.c0, under, 0);
+    s.cur = rt_stack_node_step<ROOM_CHECKED>(st, both, h0 || h1, first0 ? n.c0 : n.c1, first0 ? n.c1 : n.c0, under, 0);
 }
 template <class Stack, class Nodes>
 RT_HD void rt_trav_descend(const Nodes& nodes, RtTrav& s, Stack& st, double t_min) {

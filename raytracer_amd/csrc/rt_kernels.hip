@@ -632,10 +632,10 @@ __global__ void __launch_bounds__(RT_TREE_BLOCK) k_extend_tree(DScene sc, PassIn
                 if (at_node) rt_node_step_signed<ARRAYS>(picked, kids_at, s, st, t_min);
                 if (is_node(s.cur)) rt_node_step_signed<ARRAYS>(picked, kids_at, s, st, t_min);
             } else {
-                if (at_node) rt_trav_node_step<EXACT_NODES>(nodes, s, st, t_min);
+                if (at_node) rt_trav_node_step<EXACT_NODES, !PLAIN>(nodes, s, st, t_min); // (a PLAIN instantiation only runs on a tree whose stack need has been verified)
                 // a second step before the next look at the wave: the two ballots above cost a sixth of a step (-3.6 % kernel
                 // time; a third and fourth step bring nothing more, measured again with the relative leaf threshold)
-                if (RT_REF_TYPE(s.cur) == RT_REF_NODE) rt_trav_node_step<EXACT_NODES>(nodes, s, st, t_min);
+                if (RT_REF_TYPE(s.cur) == RT_REF_NODE) rt_trav_node_step<EXACT_NODES, !PLAIN>(nodes, s, st, t_min);
             }
         }
         RT_PHASE_CLOCK(c_nodes1);
@@ -1388,8 +1388,9 @@ int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t f
     const bool all_cached = n_cached == sc->hdr.nodes.count; // every node of the scene has a place in LDS
     out->kernel = table[exact_nodes][sphere_media][query][all_cached];
     // a tree with plain leaves: the instantiation without the code for lists and frame changes (not for a scene without a
-    // tree: its lock-step list may hold a small tree's steps, which that instantiation's list walk leaves out)
-    if (sc->plain_leaves && !exact_nodes && sphere_media && sc->hdr.world_tree != RT_REF_NONE && !(force & 8u)) {
+    // tree: its lock-step list may hold a small tree's steps, which that instantiation's list walk leaves out; and only for a
+    // tree whose stack need has been verified: its box steps push without asking for room)
+    if (sc->plain_leaves && sc->stack_verified && !exact_nodes && sphere_media && sc->hdr.world_tree != RT_REF_NONE && !(force & 8u)) {
         // (many moving spheres - one primitive in eight or more: the instantiations whose sphere test takes them along)
         const size_t prims = sc->hdr.spheres.count + sc->hdr.mspheres.count + sc->hdr.rects.count + sc->hdr.boxes.count;
         const bool mm = sc->hdr.mspheres.count * 8u >= prims && sc->hdr.mspheres.count != 0u && !(force & 32u);
@@ -1398,14 +1399,13 @@ int extend_launch_of(rt_context* ctx, const rt_scene* sc, bool query, uint32_t f
 #undef RT_PLAIN_ROW
         out->kernel = plain_tree[mm][query][all_cached];
         // every node in LDS and few enough of them: the records as fourteen arrays (rt_node_step_signed), if that fits too
-        // (its step pushes without asking for room: only for a tree whose stack need the upload has verified)
 #define RT_ARRAYS_ROW(N, M) {k_extend_tree<false, true, false, true, true, N, M>, k_extend_tree<false, true, true, true, true, N, M>}
         static const ExtendKernel arrays512[2][2] = {RT_ARRAYS_ROW(512, false), RT_ARRAYS_ROW(512, true)};
         static const ExtendKernel arrays1536[2][2] = {RT_ARRAYS_ROW(1536, false), RT_ARRAYS_ROW(1536, true)};
 #undef RT_ARRAYS_ROW
         const size_t count = sc->hdr.nodes.count;
         const uint32_t arrays = count <= 512u ? 512u : count <= 1536u ? 1536u : 0u;
-        if (all_cached && arrays != 0u && sc->stack_verified && !(force & 16u) && lds_stack_bytes + (size_t)arrays * 14u * sizeof(uint32_t) + 16 <= ctx->lds_per_block) {
+        if (all_cached && arrays != 0u && !(force & 16u) && lds_stack_bytes + (size_t)arrays * 14u * sizeof(uint32_t) + 16 <= ctx->lds_per_block) {
             out->kernel = arrays == 512u ? arrays512[mm][query] : arrays1536[mm][query];
             lds = lds_stack_bytes + (size_t)arrays * 14u * sizeof(uint32_t) + 16;
         }
@@ -1688,11 +1688,12 @@ int rt_scene_build_tree_device(rt_context* ctx, rt_scene* sc, rt_tree_stats* sta
                                         RT_REF_INDEX(h.device_tree_root), h.device_tree_leaves, RT_STACK_CAP - fixed, &res, err);
     if (rc != RT_OK) return ctx_fail(ctx, rc, err.c_str());
     sc->tree_built = true;
-    sc->stack_verified = false; // (this tree's stack need is a bound from its height and the header's figures: the traversal keeps its room check)
     if (h.device_tree_leaves >= 2u) {
         const uint32_t need = std::max(h.device_tree_need_other, res.height + h.device_tree_leaf_need) + h.device_tree_need_add;
         sc->hdr.stack_need = std::max(1u, need);
     }
+    // (a tree with plain leaves keeps at most one entry per node on the way down: the height the builder measured bounds its need)
+    sc->stack_verified = sc->plain_leaves && sc->hdr.stack_need >= res.height;
     if (stats) {
         stats->leaves = h.device_tree_leaves; stats->height = res.height; stats->key_bits = res.key_bits; stats->stack_need = sc->hdr.stack_need;
         stats->ms_collect = res.ms_collect; stats->ms_sort = res.ms_sort; stats->ms_hierarchy = res.ms_hierarchy;
