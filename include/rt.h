@@ -188,6 +188,10 @@ int rt_init(rt_context** out, int device);  /* RT_ERR_NO_DEVICE when HIP reports
 void rt_shutdown(rt_context*);
 const char* rt_last_error(const rt_context*);
 
+/* A blob is checked before it is used: version, section bounds, table indices, the steps of a lock-step tree; the world's
+ * tree, where its leaves are plain objects, is walked once - a node that is its own descendant is RT_ERR_INVALID, and a
+ * header whose stack_need the tree exceeds only costs the scene the faster traversal kernels (which push without asking for
+ * room), not the render: the general kernel reports an overflow if one happens (RT_ERR_UNSUPPORTED from the render call). */
 int rt_scene_upload(rt_context*, const void* blob, size_t nbytes, rt_scene** out);             /* host blob */
 int rt_scene_upload_from_device(rt_context*, const void* d_blob, size_t nbytes, rt_scene** out); /* blob already in HBM (after an RCCL broadcast) */
 void rt_scene_free(rt_context*, rt_scene*);
